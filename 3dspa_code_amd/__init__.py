@@ -1,0 +1,11 @@
+"""3dspa_code_amd -- MI355X-native (gfx950) 3DSPA TrackAutoEncoder3D train-step hot path.
+
+The directory name is not a Python identifier; import it as `import spa3d` (repo-root shim) or
+`importlib.import_module('3dspa_code_amd')`."""
+from . import _lib
+from .model import (ParamTree, TrackAutoEncoder3D, TrackAutoEncoderDecoderContext, TrackAutoEncoderResults, compute_loss_3d,
+                    sinusoidal_embedding)
+from .train import TrainState, create_learning_rate_schedule
+
+__all__ = ['TrackAutoEncoder3D', 'TrackAutoEncoderResults', 'TrackAutoEncoderDecoderContext', 'ParamTree', 'compute_loss_3d',
+           'sinusoidal_embedding', 'TrainState', 'create_learning_rate_schedule', '_lib']

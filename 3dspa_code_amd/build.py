@@ -1,0 +1,70 @@
+"""Build libspa3d_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build() and on first import."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libspa3d_hip.so')
+SOURCES = ['kernels.hip', 'gemm_generic.hip', 'gemm_fast.hip', 'attention.hip', 'attention_fused.hip', 'ops.hip', 'model.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
+         '-Wno-unused-variable', '-Wno-unused-but-set-variable']
+
+
+def _hipcc():
+  for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+    if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+      return c
+  raise RuntimeError('hipcc not found')
+
+
+def _stale(out, deps):
+  if not os.path.exists(out):
+    return True
+  t = os.path.getmtime(out)
+  return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+  hipcc = _hipcc()
+  hdrs = [os.path.join(CSRC, 'common.hpp'), os.path.join(HERE, '..', 'include', 'spa3d.h')]
+  objdir = os.path.join(HERE, 'build')
+  os.makedirs(objdir, exist_ok=True)
+  srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+  jobs = []
+  for s in srcs:
+    src = os.path.join(CSRC, s)
+    obj = os.path.join(objdir, s.replace('.hip', '.o'))
+    if force or _stale(obj, [src] + hdrs):
+      jobs.append((src, obj))
+
+  def cc(job):
+    src, obj = job
+    cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+    if verbose:
+      print(' '.join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+      raise RuntimeError(f'hipcc failed on {src}:\n{r.stdout}\n{r.stderr}')
+    if verbose and r.stderr.strip():
+      print(r.stderr, file=sys.stderr)
+    return obj
+
+  with ThreadPoolExecutor(max_workers=4) as ex:
+    list(ex.map(cc, jobs))
+  objs = [os.path.join(objdir, s.replace('.hip', '.o')) for s in srcs]
+  if force or jobs or _stale(LIB, objs):
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    if verbose:
+      print(' '.join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+      raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+  return LIB
+
+
+if __name__ == '__main__':
+  print(build(force='--force' in sys.argv))

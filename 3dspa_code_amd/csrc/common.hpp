@@ -1,0 +1,169 @@
+// common.hpp -- shared declarations for libspa3d_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/spa3d.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits; arithmetic is always done in f32
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+// round-to-nearest-even; a plain cast emits v_cvt_pk_bf16_f32 and keeps NaN a NaN
+// (MI355X_MICROARCH.md "Correctness boundaries")
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+template <typename T> __device__ __forceinline__ float ld(const T* p);
+template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void st(T* p, float v);
+template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float c = 0.7978845608028654f;  // sqrt(2/pi)
+  float u = c * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_tanh_grad_f(float x) {
+  const float c = 0.7978845608028654f;
+  float u = c * (x + 0.044715f * x * x * x);
+  float t = tanhf(u);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x * x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side context
+// ------------------------------------------------------------------------------------------
+struct Leaf {
+  std::string name;
+  int ndim;
+  int64_t shape[4];
+  int64_t offset;
+  int64_t numel() const { int64_t n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i]; return n; }
+};
+
+struct Arena {  // bump allocator over the caller's workspace; dry mode only counts
+  char* base = nullptr;
+  int64_t cap = 0, off = 0, peak = 0;
+  bool dry = false, overflow = false;
+  void* alloc(int64_t bytes) {
+    int64_t a = (off + 255) & ~int64_t(255);
+    off = a + bytes;
+    if (off > peak) peak = off;
+    if (dry) return (void*)(uintptr_t)(0x1000 + a);  // never dereferenced
+    if (off > cap) { overflow = true; return base; }
+    return base + a;
+  }
+  int64_t mark() const { return off; }
+  void release(int64_t m) { off = m; }
+};
+
+struct spa3d_ctx {
+  spa3d_config cfg;
+  std::vector<Leaf> leaves;
+  int64_t nparams = 0;
+  std::string err;
+  hipStream_t stream = nullptr;
+  Arena ar;
+  bool dry = false;   // orchestration runs without launching (workspace sizing)
+  int hip_err = 0;
+  int gemm_impl = 0;  // 0 auto, 1 generic only
+  int attn_impl = 0;
+};
+
+#define SPA_LAUNCH_CHECK(ctx)                                                     \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess && (ctx)->hip_err == 0) {                               \
+      (ctx)->hip_err = (int)e__;                                                  \
+      (ctx)->err = std::string("HIP launch failed at ") + __FILE__ + ":" +        \
+                   std::to_string(__LINE__) + ": " + hipGetErrorString(e__);      \
+    }                                                                             \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------
+// GEMM descriptor (generic, batched, strided).  C[b][m][n] (op)= alpha*sum_k A[b][m][k]*B[b][k][n]
+// ------------------------------------------------------------------------------------------
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_MUL_GELU_GRAD = 2 };
+struct GemmDesc {
+  const void* A; const void* B; void* C;
+  int64_t M; int32_t N; int32_t K;
+  int64_t sAm, sAk, sBk, sBn, sCm;   // element strides (C is n-contiguous)
+  int32_t nb1 = 1, nb2 = 1;          // two-level batch: blockIdx.z = b1*nb2 + b2
+  int64_t bA1 = 0, bA2 = 0, bB1 = 0, bB2 = 0, bC1 = 0, bC2 = 0;
+  float alpha = 1.f;
+  const float* bias = nullptr;       // [N] f32, added before act
+  int epi = EPI_NONE;
+  const void* aux = nullptr;         // residual (added after act) or pre-activation (EPI_MUL_GELU_GRAD); C layout, T
+  int aux_is_residual = 1;
+  int out_f32 = 0;                   // C is float regardless of T
+  int accumulate = 0;                // C += (non-atomic)
+  int atomic = 0;                    // C += via atomicAdd (f32 C only)
+  const void* Bt = nullptr;          // optional copy of B stored [N][K] (K contiguous, row stride ldBt) for the tiled kernels
+  int64_t ldBt = 0;
+};
+
+template <typename T> void gemm_generic(spa3d_ctx* c, const GemmDesc& d);
+// tiled bf16 kernels (gemm_fast.hip).  Return false if the shape/layout is not supported.
+bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d);
+bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d);
+
+// ------------------------------------------------------------------------------------------
+// elementwise / reduction kernels (kernels.hip), all asynchronous on c->stream; no-ops when c->dry
+// ------------------------------------------------------------------------------------------
+template <typename T> void k_layernorm(spa3d_ctx*, const T* x, const float* scale, T* y, float* stats, int64_t rows, int d);
+template <typename T> void k_layernorm_bwd(spa3d_ctx*, const T* x, const float* scale, const float* stats, const T* dy, T* dx,
+                                           float* dscale, int64_t rows, int d, const T* add);
+template <typename T> void k_rmsnorm_heads(spa3d_ctx*, const T* x, int64_t ldx, const float* scale, T* y, int64_t ldy, int64_t rows, int H, int Dh);
+template <typename T> void k_rmsnorm_heads_bwd(spa3d_ctx*, const T* x, int64_t ldx, const float* scale, const T* dy, int64_t lddy, T* dx,
+                                               int64_t lddx, float* dscale, int64_t rows, int H, int Dh);
+template <typename T> void k_softmax(spa3d_ctx*, T* s, const float* keymask, int64_t nseq, int H, int Sq, int Sk);
+template <typename T> void k_softmax_bwd(spa3d_ctx*, const T* p, T* dp, int64_t rows, int Sk);
+template <typename T> void k_sin_embed(spa3d_ctx*, const float* x, int64_t rows, int C, int nf, float prescale, T* out);
+template <typename T> void k_embed_tokens(spa3d_ctx*, const float* tracks, int64_t nrows, int T_, int nf, float prescale, T* sinbuf);
+template <typename T> void k_colsum(spa3d_ctx*, const T* x, int64_t rows, int n, int64_t ld, float* out /*accumulated*/);
+template <typename T> void k_gelu(spa3d_ctx*, const T* x, T* y, int64_t n);
+template <typename T> void k_add(spa3d_ctx*, T* dst, const T* src, int64_t n);
+void k_fill(spa3d_ctx*, float* p, float v, int64_t n);
+void k_zero(spa3d_ctx*, void* p, int64_t bytes);
+void k_mul(spa3d_ctx*, float* a, const float* b, int64_t n);
+template <typename T> void k_cast_from_f32(spa3d_ctx*, const float* src, T* dst, int64_t n);
+template <typename T> void k_cast_to_f32(spa3d_ctx*, const T* src, float* dst, int64_t n);
+template <typename T> void k_pack(spa3d_ctx*, const float* src, int64_t src_ld, int rows, int cols, T* dst_native, int64_t ldn, T* dst_T, int64_t ldt);
+template <typename T> void k_transpose(spa3d_ctx*, const T* src, int rows, int cols, T* dst);  // dst[c][r] = src[r][c]
+template <typename T> void k_set_readout_rows(spa3d_ctx*, T* tok, const float* readout, int64_t nseq, int S, int d);
+void k_keymask(spa3d_ctx*, const float* visible, const int32_t* boundary, int64_t nseq, int N, int T_, float* km);
+template <typename T> void k_gather_rows(spa3d_ctx*, const T* src, int64_t src_stride_rows, T* dst, int64_t n, int d);
+template <typename T> void k_scatter_rows(spa3d_ctx*, const T* src, T* dst, int64_t dst_stride_rows, int64_t n, int d);
+template <typename T> void k_compact_tokens(spa3d_ctx*, const T* tok, T* dst, int64_t nseq, int S, int d);
+template <typename T> void k_broadcast_rows(spa3d_ctx*, const float* src, int rows, int d, T* dst, int64_t B);
+template <typename T> void k_bcast_grad(spa3d_ctx*, const T* dsrc, int64_t per, int64_t B, int64_t bstride, float* dparam);
+void k_discretize(spa3d_ctx*, const float* lat, const float* noise, int discretize, float* out, float* clipmask, int64_t n);
+void k_query_embed1(spa3d_ctx*, const float* qp, int64_t nq, int nf, float track_scale, float time_scale, float* feat, int32_t* qframe);
+template <typename T> void k_assemble_readout(spa3d_ctx*, const T* qtok, const T* lat, const int32_t* qframe, int64_t B, int Q, int L, int Cl,
+                                              int D, T* seq);
+template <typename T> void k_assemble_readout_bwd(spa3d_ctx*, const T* dseq, const int32_t* qframe, int64_t B, int Q, int L, int Cl, int D,
+                                                  T* dqtok, float* dlat);
+void k_loss_fwd(spa3d_ctx*, const float* head, int64_t nq, int T_, const float* tgt, const float* tvis, float* tracks, float* vlog,
+                float* clog, float* sums);
+void k_loss_from_preds(spa3d_ctx*, const float* tracks, const float* vlog, int64_t n, const float* tgt, const float* tvis, float* sums);
+template <typename T> void k_loss_bwd(spa3d_ctx*, const float* head, int64_t nq, int T_, const float* tgt, const float* tvis,
+                                      const float* denom_dev, float l1w, float bcew, T* dhead);
+void k_vis_count(spa3d_ctx*, const float* tvis, int64_t n, float* out);
+void k_set_denom(spa3d_ctx*, const float* sums, float denom_host, float* denom_dev);
+void k_loss_finalize(spa3d_ctx*, const float* sums, const float* denom_dev, float l1w, float bcew, float* loss3);
+void k_adamw(spa3d_ctx*, float* p, const float* g, float* m, float* v, int64_t n, float lr, int64_t step, float clip, float b1, float b2,
+             float eps, float wd, float* scratch);
+void k_uniform_noise(spa3d_ctx*, float* out, int64_t n, uint32_t k0, uint32_t k1);

@@ -1,0 +1,842 @@
+// kernels.hip -- elementwise / normalisation / reduction / assembly kernels of the 3DSPA hot path (gfx950).
+// HBM-bound kernels: one wave per row where a row reduction is needed, coalesced lane-contiguous access,
+// fp32 math, T in {float, bf16_t} storage.  References are to /root/reference files.
+#include "common.hpp"
+
+#define GRID1D(n, bs) dim3((unsigned)std::min<int64_t>(((n) + (bs)-1) / (bs), 1 << 20))
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm (flax nn.LayerNorm(use_bias=False), eps 1e-6, fast variance clamped at 0) attention.py:49,76,103
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale, T* __restrict__ y,
+                                                     float* __restrict__ stats, int64_t rows, int d) {
+  const int lane = threadIdx.x & 63;
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (; row < rows; row += stride) {
+    const T* xr = x + row * d;
+    float s = 0.f, ss = 0.f;
+    for (int i = lane; i < d; i += 64) { float v = ld(xr + i); s += v; ss += v * v; }
+    s = wave_sum(s); ss = wave_sum(ss);
+    float mu = s / d;
+    float var = fmaxf(ss / d - mu * mu, 0.f);
+    float r = rsqrtf(var + 1e-6f);
+    if (stats && lane == 0) { stats[row * 2] = mu; stats[row * 2 + 1] = r; }
+    T* yr = y + row * d;
+    for (int i = lane; i < d; i += 64) st(yr + i, (ld(xr + i) - mu) * r * scale[i]);
+  }
+}
+template <typename T>
+void k_layernorm(spa3d_ctx* c, const T* x, const float* scale, T* y, float* stats, int64_t rows, int d) {
+  if (c->dry || rows == 0) return;
+  unsigned g = (unsigned)std::min<int64_t>(cdiv(rows, 4), 65536);
+  ln_fwd_kernel<T><<<g, 256, 0, c->stream>>>(x, scale, y, stats, rows, d);
+  SPA_LAUNCH_CHECK(c);
+}
+
+// dx = [add +] r*(g - mean(g) - xhat*mean(g*xhat)), g = dy*scale ; dscale += sum_rows dy*xhat   
+#define LN_MAXJ 32  // d <= 2048
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                     const float* __restrict__ stats, const T* __restrict__ dy, const T* add,
+                                                     T* dx, float* __restrict__ dscale, int64_t rows, int d) {
+  __shared__ float red[4][64 * LN_MAXJ / 4];  // reused per quarter below
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float acc[LN_MAXJ];
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) acc[j] = 0.f;
+  int64_t row = (int64_t)blockIdx.x * 4 + w;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (; row < rows; row += stride) {
+    const T* xr = x + row * d;
+    const T* dyr = dy + row * d;
+    const float mu = stats[row * 2], r = stats[row * 2 + 1];
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+      int i = lane + 64 * j;
+      if (i < d) {
+        float xh = (ld(xr + i) - mu) * r;
+        float dyv = ld(dyr + i);
+        float g = dyv * scale[i];
+        sg += g; sgx += g * xh;
+        acc[j] += dyv * xh;
+      }
+    }
+    sg = wave_sum(sg) / d; sgx = wave_sum(sgx) / d;
+    T* dxr = dx + row * d;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+      int i = lane + 64 * j;
+      if (i < d) {
+        float xh = (ld(xr + i) - mu) * r;
+        float g = ld(dyr + i) * scale[i];
+        float v = r * (g - sg - xh * sgx);
+        if (add) v += ld(add + row * d + i);
+        st(dxr + i, v);
+      }
+    }
+  }
+  // block reduce acc over the 4 waves, 8 columns-groups at a time to bound LDS
+  for (int j0 = 0; j0 < LN_MAXJ; j0 += 8) {
+    if (j0 * 64 >= d) break;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[w][j * 64 + lane] = acc[j0 + j];
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int i = lane + 64 * (j0 + j);
+        if (i < d) {
+          float s = red[0][j * 64 + lane] + red[1][j * 64 + lane] + red[2][j * 64 + lane] + red[3][j * 64 + lane];
+          atomicAdd(dscale + i, s);
+        }
+      }
+    }
+  }
+}
+template <typename T>
+void k_layernorm_bwd(spa3d_ctx* c, const T* x, const float* scale, const float* stats, const T* dy, T* dx, float* dscale,
+                     int64_t rows, int d, const T* add) {
+  if (c->dry || rows == 0) return;
+  unsigned g = (unsigned)std::min<int64_t>(cdiv(rows, 4), 2048);
+  ln_bwd_kernel<T><<<g, 256, 0, c->stream>>>(x, scale, stats, dy, add, dx, dscale, rows, d);
+  SPA_LAUNCH_CHECK(c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-head RMSNorm over Dh (flax nn.RMSNorm eps 1e-6) attention.py:166-167.  one wave per (row, head)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rms_heads_fwd_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ scale,
+                                                            T* __restrict__ y, int64_t ldy, int64_t rows, int H, int Dh) {
+  const int lane = threadIdx.x & 63;
+  int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t n = rows * H, stride = (int64_t)gridDim.x * 4;
+  for (; item < n; item += stride) {
+    int64_t row = item / H; int h = (int)(item - row * H);
+    const T* xr = x + row * ldx + h * Dh;
+    float v0 = lane < Dh ? ld(xr + lane) : 0.f;
+    float v1 = lane + 64 < Dh ? ld(xr + lane + 64) : 0.f;
+    float ms = wave_sum(v0 * v0 + v1 * v1) / Dh;
+    float r = rsqrtf(ms + 1e-6f);
+    T* yr = y + row * ldy + h * Dh;
+    if (lane < Dh) st(yr + lane, v0 * r * scale[lane]);
+    if (lane + 64 < Dh) st(yr + lane + 64, v1 * r * scale[lane + 64]);
+  }
+}
+template <typename T>
+void k_rmsnorm_heads(spa3d_ctx* c, const T* x, int64_t ldx, const float* scale, T* y, int64_t ldy, int64_t rows, int H, int Dh) {
+  if (c->dry || rows == 0) return;
+  unsigned g = (unsigned)std::min<int64_t>(cdiv(rows * H, 4), 65536);
+  rms_heads_fwd_kernel<T><<<g, 256, 0, c->stream>>>(x, ldx, scale, y, ldy, rows, H, Dh);
+  SPA_LAUNCH_CHECK(c);
+}
+// dx = r*(g - xhat*mean(g*xhat)), g=dy*scale ; dscale += sum dy*xhat
+template <typename T>
+__global__ __launch_bounds__(256) void rms_heads_bwd_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ scale,
+                                                            const T* __restrict__ dy, int64_t lddy, T* __restrict__ dx, int64_t lddx,
+                                                            float* __restrict__ dscale, int64_t rows, int H, int Dh) {
+  __shared__ float red[4][128];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float a0 = 0.f, a1 = 0.f;
+  int64_t item = (int64_t)blockIdx.x * 4 + w;
+  const int64_t n = rows * H, stride = (int64_t)gridDim.x * 4;
+  const float s0 = lane < Dh ? scale[lane] : 0.f, s1 = lane + 64 < Dh ? scale[lane + 64] : 0.f;
+  for (; item < n; item += stride) {
+    int64_t row = item / H; int h = (int)(item - row * H);
+    const T* xr = x + row * ldx + h * Dh;
+    const T* dyr = dy + row * lddy + h * Dh;
+    float v0 = lane < Dh ? ld(xr + lane) : 0.f, v1 = lane + 64 < Dh ? ld(xr + lane + 64) : 0.f;
+    float d0 = lane < Dh ? ld(dyr + lane) : 0.f, d1 = lane + 64 < Dh ? ld(dyr + lane + 64) : 0.f;
+    float r = rsqrtf(wave_sum(v0 * v0 + v1 * v1) / Dh + 1e-6f);
+    float xh0 = v0 * r, xh1 = v1 * r;
+    float g0 = d0 * s0, g1 = d1 * s1;
+    float mg = wave_sum(g0 * xh0 + g1 * xh1) / Dh;
+    a0 += d0 * xh0; a1 += d1 * xh1;
+    T* dxr = dx + row * lddx + h * Dh;
+    if (lane < Dh) st(dxr + lane, r * (g0 - xh0 * mg));
+    if (lane + 64 < Dh) st(dxr + lane + 64, r * (g1 - xh1 * mg));
+  }
+  red[w][lane] = a0; red[w][lane + 64] = a1;
+  __syncthreads();
+  if (w == 0) {
+    if (lane < Dh) atomicAdd(dscale + lane, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+    if (lane + 64 < Dh) atomicAdd(dscale + lane + 64, red[0][lane + 64] + red[1][lane + 64] + red[2][lane + 64] + red[3][lane + 64]);
+  }
+}
+template <typename T>
+void k_rmsnorm_heads_bwd(spa3d_ctx* c, const T* x, int64_t ldx, const float* scale, const T* dy, int64_t lddy, T* dx, int64_t lddx,
+                         float* dscale, int64_t rows, int H, int Dh) {
+  if (c->dry || rows == 0) return;
+  unsigned g = (unsigned)std::min<int64_t>(cdiv(rows * H, 4), 2048);
+  rms_heads_bwd_kernel<T><<<g, 256, 0, c->stream>>>(x, ldx, scale, dy, lddy, dx, lddx, dscale, rows, H, Dh);
+  SPA_LAUNCH_CHECK(c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax over keys with key mask: where(mask, logit, finfo.min) -> softmax (flax dot_product_attention)
+// s: [nseq][H][Sq][Sk] in place.  one wave per row.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_kernel(T* __restrict__ s, const float* __restrict__ km, int64_t nseq, int H, int Sq, int Sk) {
+  const int lane = threadIdx.x & 63;
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nrows = nseq * H * Sq, stride = (int64_t)gridDim.x * 4;
+  for (; row < nrows; row += stride) {
+    int64_t seq = row / ((int64_t)H * Sq);
+    T* sr = s + row * Sk;
+    const float* kmr = km ? km + seq * Sk : nullptr;
+    float m = -3.4028234663852886e38f;
+    for (int k = lane; k < Sk; k += 64) {
+      float v = ld(sr + k);
+      if (kmr && kmr[k] == 0.f) v = -3.4028234663852886e38f;
+      m = fmaxf(m, v);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int k = lane; k < Sk; k += 64) {
+      float v = ld(sr + k);
+      if (kmr && kmr[k] == 0.f) v = -3.4028234663852886e38f;
+      sum += expf(v - m);
+    }
+    sum = wave_sum(sum);
+    float inv = 1.f / sum;
+    for (int k = lane; k < Sk; k += 64) {
+      float v = ld(sr + k);
+      if (kmr && kmr[k] == 0.f) v = -3.4028234663852886e38f;
+      st(sr + k, expf(v - m) * inv);
+    }
+  }
+}
+template <typename T>
+void k_softmax(spa3d_ctx* c, T* s, const float* keymask, int64_t nseq, int H, int Sq, int Sk) {
+  if (c->dry || nseq == 0) return;
+  unsigned g = (unsigned)std::min<int64_t>(cdiv(nseq * H * Sq, 4), 65536);
+  softmax_kernel<T><<<g, 256, 0, c->stream>>>(s, keymask, nseq, H, Sq, Sk);
+  SPA_LAUNCH_CHECK(c);
+}
+// dS = P o (dP - rowsum(dP o P)), in place on dp
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ p, T* __restrict__ dp, int64_t rows, int Sk) {
+  const int lane = threadIdx.x & 63;
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (; row < rows; row += stride) {
+    const T* pr = p + row * Sk; T* dr = dp + row * Sk;
+    float s = 0.f;
+    for (int k = lane; k < Sk; k += 64) s += ld(pr + k) * ld(dr + k);
+    s = wave_sum(s);
+    for (int k = lane; k < Sk; k += 64) { float pv = ld(pr + k); st(dr + k, pv * (ld(dr + k) - s)); }
+  }
+}
+template <typename T>
+void k_softmax_bwd(spa3d_ctx* c, const T* p, T* dp, int64_t rows, int Sk) {
+  if (c->dry || rows == 0) return;
+  unsigned g = (unsigned)std::min<int64_t>(cdiv(rows, 4), 65536);
+  softmax_bwd_kernel<T><<<g, 256, 0, c->stream>>>(p, dp, rows, Sk);
+  SPA_LAUNCH_CHECK(c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// SinusoidalEmbedding (track_autoencoder.py:18-38): v = fl32(x*s_f); out = sin([v, fl32(v + fl32(pi/2))])
+// layout "(coords d)": out[r][c*2nf + f] , out[r][c*2nf + nf + f].  Never fused to fma, never cos.
+// ---------------------------------------------------------------------------------------------
+struct SinScales { float s[64]; };
+static SinScales make_scales(int nf) {
+  SinScales sc;
+  for (int i = 0; i < 64; ++i) sc.s[i] = i < nf ? (float)pow(2.0, (double)i / 3.0) : 0.f;
+  return sc;
+}
+__device__ __forceinline__ float sin_feat(float x, float s, bool shifted) {
+  float v = __fmul_rn(x, s);
+  if (shifted) v = __fadd_rn(v, 1.57079637050628662109375f);  // fl32(0.5*pi)
+  return sinf(v);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void sin_embed_kernel(const float* __restrict__ x, int64_t rows, int C, int nf, float prescale,
+                                                        SinScales sc, T* __restrict__ out) {
+  const int W = C * 2 * nf;
+  const int64_t n = rows * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    int64_t r = i / W; int j = (int)(i - r * W);
+    int cc = j / (2 * nf); int f = j - cc * 2 * nf;
+    float xv = x[r * C + cc] / prescale;
+    st(out + i, sin_feat(xv, sc.s[f < nf ? f : f - nf], f >= nf));
+  }
+}
+template <typename T>
+void k_sin_embed(spa3d_ctx* c, const float* x, int64_t rows, int C, int nf, float prescale, T* out) {
+  if (c->dry || rows == 0) return;
+  sin_embed_kernel<T><<<GRID1D(rows * C * 2 * nf, 256), 256, 0, c->stream>>>(x, rows, C, nf, prescale, make_scales(nf), out);
+  SPA_LAUNCH_CHECK(c);
+}
+
+// E1+E2 for the track tokens (track_autoencoder_3d.py:126-134): x4 = [x,y,z,t/T] -> sinbuf[nseq*T][4*2nf]
+template <typename T>
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const float* __restrict__ tracks, int64_t nrows, int T_, int nf, float prescale,
+                                                           SinScales sc, T* __restrict__ out) {
+  const int W = 4 * 2 * nf;
+  const int64_t n = nrows * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    int64_t r = i / W; int j = (int)(i - r * W);
+    int cc = j / (2 * nf); int f = j - cc * 2 * nf;
+    float xv;
+    if (cc < 3) xv = tracks[r * 3 + cc];
+    else xv = (float)(int)(r % T_) / (float)T_;  // jnp.arange(T)/T
+    xv = xv / prescale;
+    st(out + i, sin_feat(xv, sc.s[f < nf ? f : f - nf], f >= nf));
+  }
+}
+template <typename T>
+void k_embed_tokens(spa3d_ctx* c, const float* tracks, int64_t nrows, int T_, int nf, float prescale, T* sinbuf) {
+  if (c->dry || nrows == 0) return;
+  embed_tokens_kernel<T><<<GRID1D(nrows * 8 * nf, 256), 256, 0, c->stream>>>(tracks, nrows, T_, nf, prescale, make_scales(nf), sinbuf);
+  SPA_LAUNCH_CHECK(c);
+}
+
+// get_decoder_context + first-level query features (track_autoencoder_3d.py:209-233,265-272):
+// feat[q][0:6nf] = sin-embed(xyz/track_scale); feat[q][6nf] = floor(round(t)/time_scale); qframe = round(t) (half-even)
+__global__ __launch_bounds__(256) void query_embed1_kernel(const float* __restrict__ qp, int64_t nq, int nf, float track_scale,
+                                                           float time_scale, SinScales sc, float* __restrict__ feat, int32_t* __restrict__ qframe) {
+  const int W = 6 * nf + 1;
+  const int64_t n = nq * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    int64_t q = i / W; int j = (int)(i - q * W);
+    if (j == 6 * nf) {
+      int32_t fr = (int32_t)rintf(qp[q * 4]);
+      qframe[q] = fr;
+      feat[i] = floorf((float)fr / time_scale);
+    } else {
+      int cc = j / (2 * nf); int f = j - cc * 2 * nf;
+      float xv = qp[q * 4 + 1 + cc] / track_scale;
+      feat[i] = sin_feat(xv, sc.s[f < nf ? f : f - nf], f >= nf);
+    }
+  }
+}
+void k_query_embed1(spa3d_ctx* c, const float* qp, int64_t nq, int nf, float track_scale, float time_scale, float* feat, int32_t* qframe) {
+  if (c->dry || nq == 0) return;
+  query_embed1_kernel<<<GRID1D(nq * (6 * nf + 1), 256), 256, 0, c->stream>>>(qp, nq, nf, track_scale, time_scale, make_scales(nf), feat, qframe);
+  SPA_LAUNCH_CHECK(c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, int64_t rows, int n, int64_t ld_, float* __restrict__ out, int64_t rows_per_block) {
+  // block (64 cols x 4 row-lanes); grid (ceil(n/64), row_splits)
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = std::min<int64_t>(rows, r0 + rows_per_block);
+  float s = 0.f;
+  if (col < n) for (int64_t r = r0 + w; r < r1; r += 4) s += ld(x + r * ld_ + col);
+  red[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && col < n) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+template <typename T>
+void k_colsum(spa3d_ctx* c, const T* x, int64_t rows, int n, int64_t ld_, float* out) {
+  if (c->dry || rows == 0) return;
+  int64_t splits = std::max<int64_t>(1, std::min<int64_t>(cdiv(rows, 256), 1024 / std::max<int64_t>(1, cdiv(n, 64)) + 1));
+  int64_t rpb = cdiv(rows, splits);
+  colsum_kernel<T><<<dim3((unsigned)cdiv(n, 64), (unsigned)cdiv(rows, rpb)), 256, 0, c->stream>>>(x, rows, n, ld_, out, rpb);
+  SPA_LAUNCH_CHECK(c);
+}
+
+template <typename T>
+__global__ void gelu_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) st(y + i, gelu_tanh_f(ld(x + i)));
+}
+template <typename T> void k_gelu(spa3d_ctx* c, const T* x, T* y, int64_t n) {
+  if (c->dry || n == 0) return;
+  gelu_kernel<T><<<GRID1D(n, 256), 256, 0, c->stream>>>(x, y, n); SPA_LAUNCH_CHECK(c);
+}
+template <typename T>
+__global__ void add_kernel(T* __restrict__ dst, const T* __restrict__ src, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) st(dst + i, ld(dst + i) + ld(src + i));
+}
+template <typename T> void k_add(spa3d_ctx* c, T* dst, const T* src, int64_t n) {
+  if (c->dry || n == 0) return;
+  add_kernel<T><<<GRID1D(n, 256), 256, 0, c->stream>>>(dst, src, n); SPA_LAUNCH_CHECK(c);
+}
+__global__ void fill_kernel(float* p, float v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
+}
+void k_fill(spa3d_ctx* c, float* p, float v, int64_t n) {
+  if (c->dry || n == 0) return;
+  fill_kernel<<<GRID1D(n, 256), 256, 0, c->stream>>>(p, v, n); SPA_LAUNCH_CHECK(c);
+}
+void k_zero(spa3d_ctx* c, void* p, int64_t bytes) {
+  if (c->dry || bytes == 0) return;
+  hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, c->stream);
+  if (e != hipSuccess && !c->hip_err) { c->hip_err = (int)e; c->err = std::string("hipMemsetAsync: ") + hipGetErrorString(e); }
+}
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ s, T* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) st(d + i, s[i]);
+}
+template <typename T> void k_cast_from_f32(spa3d_ctx* c, const float* s, T* d, int64_t n) {
+  if (c->dry || n == 0) return;
+  cast_from_f32_kernel<T><<<GRID1D(n, 256), 256, 0, c->stream>>>(s, d, n); SPA_LAUNCH_CHECK(c);
+}
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ s, float* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = ld(s + i);
+}
+template <typename T> void k_cast_to_f32(spa3d_ctx* c, const T* s, float* d, int64_t n) {
+  if (c->dry || n == 0) return;
+  cast_to_f32_kernel<T><<<GRID1D(n, 256), 256, 0, c->stream>>>(s, d, n); SPA_LAUNCH_CHECK(c);
+}
+
+// weight shadows: src f32 [rows][cols] (row stride src_ld) -> native T [rows][ldn-strided], transposed T [cols][ldt-strided]
+template <typename T>
+__global__ void pack_kernel(const float* __restrict__ src, int64_t src_ld, int rows, int cols, T* dn, int64_t ldn, T* dt, int64_t ldt) {
+  __shared__ float tile[32][33];
+  int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    int r = r0 + i, cc = c0 + tx;
+    float v = (r < rows && cc < cols) ? src[(int64_t)r * src_ld + cc] : 0.f;
+    tile[i][tx] = v;
+    if (dn && r < rows && cc < cols) st(dn + (int64_t)r * ldn + cc, v);
+  }
+  __syncthreads();
+  if (dt)
+    for (int i = ty; i < 32; i += 8) {
+      int cc = c0 + i, r = r0 + tx;
+      if (r < rows && cc < cols) st(dt + (int64_t)cc * ldt + r, tile[tx][i]);
+    }
+}
+template <typename T>
+void k_pack(spa3d_ctx* c, const float* src, int64_t src_ld, int rows, int cols, T* dn, int64_t ldn, T* dt, int64_t ldt) {
+  if (c->dry) return;
+  pack_kernel<T><<<dim3((unsigned)cdiv(cols, 32), (unsigned)cdiv(rows, 32)), 256, 0, c->stream>>>(src, src_ld, rows, cols, dn, ldn, dt, ldt);
+  SPA_LAUNCH_CHECK(c);
+}
+
+template <typename T>
+__global__ void transpose_kernel(const T* __restrict__ src, int rows, int cols, T* __restrict__ dst) {
+  __shared__ T tile[32][33];
+  int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = src[(int64_t)(r0 + i) * cols + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) if (c0 + i < cols && r0 + tx < rows) dst[(int64_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+template <typename T> void k_transpose(spa3d_ctx* c, const T* src, int rows, int cols, T* dst) {
+  if (c->dry) return;
+  transpose_kernel<T><<<dim3((unsigned)cdiv(cols, 32), (unsigned)cdiv(rows, 32)), 256, 0, c->stream>>>(src, rows, cols, dst);
+  SPA_LAUNCH_CHECK(c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// token bookkeeping
+// ---------------------------------------------------------------------------------------------
+// tok[seq][0][:] = readout param (track_autoencoder_3d.py:161-165)
+template <typename T>
+__global__ void set_readout_kernel(T* tok, const float* __restrict__ ro, int64_t nseq, int S, int d) {
+  const int64_t n = nseq * d;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    int64_t s = i / d; int j = (int)(i - s * d);
+    st(tok + s * S * d + j, ro[j]);
+  }
+}
+template <typename T> void k_set_readout_rows(spa3d_ctx* c, T* tok, const float* readout, int64_t nseq, int S, int d) {
+  if (c->dry || nseq == 0) return;
+  set_readout_kernel<T><<<GRID1D(nseq * d, 256), 256, 0, c->stream>>>(tok, readout, nseq, S, d); SPA_LAUNCH_CHECK(c);
+}
+// key mask (repairs R2/R3): km[seq][0]=1 ; km[seq][1+t] = visible[seq][t]!=0 && t < boundary[b]
+__global__ void keymask_kernel(const float* __restrict__ vis, const int32_t* __restrict__ boundary, int64_t nseq, int N, int T_, float* km) {
+  const int S = T_ + 1;
+  const int64_t n = nseq * S;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    int64_t s = i / S; int k = (int)(i - s * S);
+    float v = 1.f;
+    if (k > 0) { int t = k - 1; v = (vis[s * T_ + t] != 0.f && t < boundary[s / N]) ? 1.f : 0.f; }
+    km[i] = v;
+  }
+}
+void k_keymask(spa3d_ctx* c, const float* visible, const int32_t* boundary, int64_t nseq, int N, int T_, float* km) {
+  if (c->dry || nseq == 0) return;
+  keymask_kernel<<<GRID1D(nseq * (T_ + 1), 256), 256, 0, c->stream>>>(visible, boundary, nseq, N, T_, km); SPA_LAUNCH_CHECK(c);
+}
+// dst[i][:] = src[i*stride_rows][:]
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ src, int64_t srows, T* __restrict__ dst, int64_t n, int d) {
+  const int64_t tot = n * d;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    int64_t r = i / d; int j = (int)(i - r * d);
+    dst[i] = src[r * srows * d + j];
+  }
+}
+template <typename T> void k_gather_rows(spa3d_ctx* c, const T* src, int64_t srows, T* dst, int64_t n, int d) {
+  if (c->dry || n == 0) return;
+  gather_rows_kernel<T><<<GRID1D(n * d, 256), 256, 0, c->stream>>>(src, srows, dst, n, d); SPA_LAUNCH_CHECK(c);
+}
+template <typename T>
+__global__ void scatter_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t drows, int64_t n, int d) {
+  const int64_t tot = n * d;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    int64_t r = i / d; int j = (int)(i - r * d);
+    dst[r * drows * d + j] = src[i];
+  }
+}
+template <typename T> void k_scatter_rows(spa3d_ctx* c, const T* src, T* dst, int64_t drows, int64_t n, int d) {
+  if (c->dry || n == 0) return;
+  scatter_rows_kernel<T><<<GRID1D(n * d, 256), 256, 0, c->stream>>>(src, dst, drows, n, d); SPA_LAUNCH_CHECK(c);
+}
+// copy rows 1..S-1 of each sequence into a compact [nseq*(S-1)][d] buffer (drop the readout row)
+template <typename T>
+__global__ void compact_tokens_kernel(const T* __restrict__ tok, T* __restrict__ dst, int64_t nseq, int S, int d) {
+  const int64_t tot = nseq * (S - 1) * d;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    int64_t r = i / d; int j = (int)(i - r * d);
+    int64_t s = r / (S - 1); int t = (int)(r - s * (S - 1));
+    dst[i] = tok[(s * S + 1 + t) * d + j];
+  }
+}
+template <typename T> void k_compact_tokens(spa3d_ctx* c, const T* tok, T* dst, int64_t nseq, int S, int d) {
+  if (c->dry || nseq == 0) return;
+  compact_tokens_kernel<T><<<GRID1D(nseq * (S - 1) * d, 256), 256, 0, c->stream>>>(tok, dst, nseq, S, d); SPA_LAUNCH_CHECK(c);
+}
+// ParamStateInit broadcast (track_autoencoder.py:41-53) and its gradient
+template <typename T>
+__global__ void bcast_rows_kernel(const float* __restrict__ src, int64_t per, T* __restrict__ dst, int64_t B) {
+  const int64_t tot = per * B;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) st(dst + i, src[i % per]);
+}
+template <typename T> void k_broadcast_rows(spa3d_ctx* c, const float* src, int rows, int d, T* dst, int64_t B) {
+  if (c->dry || B == 0) return;
+  bcast_rows_kernel<T><<<GRID1D((int64_t)rows * d * B, 256), 256, 0, c->stream>>>(src, (int64_t)rows * d, dst, B); SPA_LAUNCH_CHECK(c);
+}
+template <typename T>
+__global__ void bcast_grad_kernel(const T* __restrict__ dsrc, int64_t per, int64_t B, int64_t bstride, float* __restrict__ dparam) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int64_t b = 0; b < B; ++b) s += ld(dsrc + b * bstride + i);
+    dparam[i] += s;
+  }
+}
+// dparam[per] += sum_b dsrc[b*bstride + :per]
+template <typename T> void k_bcast_grad(spa3d_ctx* c, const T* dsrc, int64_t per, int64_t B, int64_t bstride, float* dparam) {
+  if (c->dry || B == 0) return;
+  bcast_grad_kernel<T><<<GRID1D(per, 256), 256, 0, c->stream>>>(dsrc, per, B, bstride, dparam); SPA_LAUNCH_CHECK(c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// D1: clip, discretise, fixed noise, straight-through (track_autoencoder_3d.py:251-260)
+// out = l - (l - q)  (same op order as the reference);  clipmask = 1[-1<=raw<=1] for the backward
+// ---------------------------------------------------------------------------------------------
+__global__ void discretize_kernel(const float* __restrict__ lat, const float* __restrict__ noise, int disc, float* __restrict__ out,
+                                  float* __restrict__ clipmask, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float raw = lat[i];
+    float l = fminf(fmaxf(raw, -1.f), 1.f);
+    if (clipmask) clipmask[i] = (raw >= -1.f && raw <= 1.f) ? 1.f : 0.f;
+    if (disc) {
+      float q = rintf(__fmul_rn(l, 128.f)) / 128.f;
+      q = __fsub_rn(__fadd_rn(q, noise[i] / 128.f), 1.0f / 256.0f);
+      l = __fsub_rn(l, __fsub_rn(l, q));
+    }
+    out[i] = l;
+  }
+}
+void k_discretize(spa3d_ctx* c, const float* lat, const float* noise, int discretize, float* out, float* clipmask, int64_t n) {
+  if (c->dry || n == 0) return;
+  discretize_kernel<<<GRID1D(n, 256), 256, 0, c->stream>>>(lat, noise, discretize, out, clipmask, n); SPA_LAUNCH_CHECK(c);
+}
+__global__ void mul_kernel(float* __restrict__ a, const float* __restrict__ b, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a[i] *= b[i];
+}
+void k_mul(spa3d_ctx* c, float* a, const float* b, int64_t n) {
+  if (c->dry || n == 0) return;
+  mul_kernel<<<GRID1D(n, 256), 256, 0, c->stream>>>(a, b, n); SPA_LAUNCH_CHECK(c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// D4-D6: readout sequence assembly without materialising tile/eye (track_autoencoder_3d.py:235-246,276-284)
+// seq[b][q][0][:] = qtok[b][q][:] ; seq[b][q][1+n][c<Cl] = lat[b][n][c] ; seq[b][q][1+n][Cl+dd] = lat[b][n][dd+5*t_q] or 0
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void assemble_kernel(const T* __restrict__ qtok, const T* __restrict__ lat, const int32_t* __restrict__ qframe, int64_t BQ, int Q,
+                                int L, int Cl, int D, T* __restrict__ seq) {
+  const int64_t tot = BQ * (L + 1) * D;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    int64_t row = i / D; int j = (int)(i - row * D);
+    int64_t bq = row / (L + 1); int tkn = (int)(row - bq * (L + 1));
+    T v;
+    if (tkn == 0) v = qtok[bq * D + j];
+    else {
+      int64_t b = bq / Q; int n = tkn - 1;
+      const T* lr = lat + (b * L + n) * Cl;
+      if (j < Cl) v = lr[j];
+      else {
+        int64_t cc = (int64_t)(j - Cl) + 5 * (int64_t)qframe[bq];
+        if (cc >= 0 && cc < Cl) v = lr[cc]; else { T z; st(&z, 0.f); v = z; }
+      }
+    }
+    seq[i] = v;
+  }
+}
+template <typename T>
+void k_assemble_readout(spa3d_ctx* c, const T* qtok, const T* lat, const int32_t* qframe, int64_t B, int Q, int L, int Cl, int D, T* seq) {
+  if (c->dry || B == 0) return;
+  assemble_kernel<T><<<GRID1D(B * Q * (L + 1) * D, 256), 256, 0, c->stream>>>(qtok, lat, qframe, B * Q, Q, L, Cl, D, seq);
+  SPA_LAUNCH_CHECK(c);
+}
+// backward: dqtok = dseq[:, :, 0, :] ; dlat[b][n][c] = sum_q dseq[b][q][1+n][c] + sum_q dseq[b][q][1+n][Cl + c-5t_q] 1[0<=c-5t_q<D-Cl]
+template <typename T>
+__global__ void assemble_bwd_lat_kernel(const T* __restrict__ dseq, const int32_t* __restrict__ qframe, int64_t B, int Q, int L, int Cl,
+                                        int D, float* __restrict__ dlat) {
+  const int64_t tot = B * L * Cl;
+  const int Wd = D - Cl;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    int64_t bn = i / Cl; int cc = (int)(i - bn * Cl);
+    int64_t b = bn / L; int n = (int)(bn - b * L);
+    float s = 0.f;
+    for (int q = 0; q < Q; ++q) {
+      const T* r = dseq + (((b * Q + q) * (L + 1)) + 1 + n) * D;
+      s += ld(r + cc);
+      int64_t dd = (int64_t)cc - 5 * (int64_t)qframe[b * Q + q];
+      if (dd >= 0 && dd < Wd) s += ld(r + Cl + dd);
+    }
+    dlat[i] = s;
+  }
+}
+template <typename T>
+void k_assemble_readout_bwd(spa3d_ctx* c, const T* dseq, const int32_t* qframe, int64_t B, int Q, int L, int Cl, int D, T* dqtok,
+                            float* dlat) {
+  if (c->dry || B == 0) return;
+  k_gather_rows<T>(c, dseq, L + 1, dqtok, B * Q, D);
+  assemble_bwd_lat_kernel<T><<<GRID1D(B * L * Cl, 256), 256, 0, c->stream>>>(dseq, qframe, B, Q, L, Cl, D, dlat);
+  SPA_LAUNCH_CHECK(c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// D8 head split + compute_loss_3d (track_autoencoder_3d.py:289-301, train.py:96-129)
+// head[q][c*T+t], c<3 coords (coordinate-major), c==3 visibility logit
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float log_sigmoid_f(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
+__global__ __launch_bounds__(256) void head_loss_fwd_kernel(const float* __restrict__ head, int64_t nq, int T_, const float* __restrict__ tgt,
+                                                            const float* __restrict__ tvis, float* __restrict__ tracks,
+                                                            float* __restrict__ vlog, float* __restrict__ clog, float* __restrict__ sums) {
+  __shared__ float red[3][4];
+  float pn = 0.f, bn = 0.f;
+  const int64_t n = nq * T_;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    int64_t q = i / T_; int t = (int)(i - q * T_);
+    const float* hr = head + q * 4 * T_;
+    float px = hr[t], py = hr[T_ + t], pz = hr[2 * T_ + t], lg = hr[3 * T_ + t];
+    if (tracks) { tracks[i * 3] = px; tracks[i * 3 + 1] = py; tracks[i * 3 + 2] = pz; }
+    if (vlog) vlog[i] = lg;
+    if (clog) clog[i] = 0.f;
+    if (tgt) {
+      float y = tvis[i];
+      pn += (fabsf(px - tgt[i * 3]) + fabsf(py - tgt[i * 3 + 1]) + fabsf(pz - tgt[i * 3 + 2])) * y;
+      bn += -y * log_sigmoid_f(lg) - (1.f - y) * log_sigmoid_f(-lg);
+    }
+  }
+  if (!tgt) return;
+  pn = wave_sum(pn); bn = wave_sum(bn);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][w] = pn; red[1][w] = bn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(sums + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(sums + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+void k_loss_fwd(spa3d_ctx* c, const float* head, int64_t nq, int T_, const float* tgt, const float* tvis, float* tracks, float* vlog,
+                float* clog, float* sums) {
+  if (c->dry || nq == 0) return;
+  unsigned g = (unsigned)std::min<int64_t>(cdiv(nq * T_, 256), 4096);
+  head_loss_fwd_kernel<<<g, 256, 0, c->stream>>>(head, nq, T_, tgt, tvis, tracks, vlog, clog, sums);
+  SPA_LAUNCH_CHECK(c);
+}
+// same numerators from already-split predictions (spa3d_loss entry point)
+__global__ __launch_bounds__(256) void loss_from_preds_kernel(const float* __restrict__ tracks, const float* __restrict__ vlog, int64_t n,
+                                                              const float* __restrict__ tgt, const float* __restrict__ tvis, float* sums) {
+  __shared__ float red[2][4];
+  float pn = 0.f, bn = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float y = tvis[i], lg = vlog[i];
+    pn += (fabsf(tracks[i * 3] - tgt[i * 3]) + fabsf(tracks[i * 3 + 1] - tgt[i * 3 + 1]) + fabsf(tracks[i * 3 + 2] - tgt[i * 3 + 2])) * y;
+    bn += -y * log_sigmoid_f(lg) - (1.f - y) * log_sigmoid_f(-lg);
+  }
+  pn = wave_sum(pn); bn = wave_sum(bn);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][w] = pn; red[1][w] = bn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(sums + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(sums + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+void k_loss_from_preds(spa3d_ctx* c, const float* tracks, const float* vlog, int64_t n, const float* tgt, const float* tvis, float* sums) {
+  if (c->dry || n == 0) return;
+  unsigned g = (unsigned)std::min<int64_t>(cdiv(n, 256), 4096);
+  loss_from_preds_kernel<<<g, 256, 0, c->stream>>>(tracks, vlog, n, tgt, tvis, sums);
+  SPA_LAUNCH_CHECK(c);
+}
+__global__ __launch_bounds__(256) void vis_count_kernel(const float* __restrict__ v, int64_t n, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += v[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+void k_vis_count(spa3d_ctx* c, const float* tvis, int64_t n, float* out) {
+  if (c->dry || n == 0) return;
+  unsigned g = (unsigned)std::min<int64_t>(cdiv(n, 256), 1024);
+  vis_count_kernel<<<g, 256, 0, c->stream>>>(tvis, n, out); SPA_LAUNCH_CHECK(c);
+}
+// sums = {pos_num, bce_num, vis_cnt}; denom_dev = denom_host>0 ? denom_host : max(vis_cnt,1)
+__global__ void set_denom_kernel(const float* sums, float denom_host, float* denom_dev) {
+  *denom_dev = denom_host > 0.f ? denom_host : fmaxf(sums[2], 1.f);
+}
+void k_set_denom(spa3d_ctx* c, const float* sums, float denom_host, float* denom_dev) {
+  if (c->dry) return;
+  set_denom_kernel<<<1, 1, 0, c->stream>>>(sums, denom_host, denom_dev); SPA_LAUNCH_CHECK(c);
+}
+__global__ void loss_finalize_kernel(const float* sums, const float* denom_dev, float l1w, float bcew, float* loss3) {
+  float d = *denom_dev;
+  float pos = sums[0] / d, vis = sums[1] / d;
+  loss3[0] = l1w * pos + bcew * vis; loss3[1] = pos; loss3[2] = vis;
+}
+void k_loss_finalize(spa3d_ctx* c, const float* sums, const float* denom_dev, float l1w, float bcew, float* loss3) {
+  if (c->dry) return;
+  loss_finalize_kernel<<<1, 1, 0, c->stream>>>(sums, denom_dev, l1w, bcew, loss3); SPA_LAUNCH_CHECK(c);
+}
+// d head: l1w*sign(pred-tgt)*vis/denom ; bcew*(sigmoid(l)-y)/denom ; sign(0)=0
+template <typename T>
+__global__ void loss_bwd_kernel(const float* __restrict__ head, int64_t nq, int T_, const float* __restrict__ tgt,
+                                const float* __restrict__ tvis, const float* __restrict__ denom_dev, float l1w, float bcew, T* __restrict__ dhead) {
+  const float inv = 1.f / *denom_dev;
+  const int64_t n = nq * 4 * T_;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    int64_t q = i / (4 * T_); int j = (int)(i - q * 4 * T_);
+    int cc = j / T_, t = j - cc * T_;
+    float y = tvis[q * T_ + t], g;
+    if (cc < 3) {
+      float df = head[i] - tgt[(q * T_ + t) * 3 + cc];
+      g = l1w * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * y * inv;
+    } else {
+      float l = head[i];
+      g = bcew * (1.f / (1.f + expf(-l)) - y) * inv;
+    }
+    st(dhead + i, g);
+  }
+}
+template <typename T>
+void k_loss_bwd(spa3d_ctx* c, const float* head, int64_t nq, int T_, const float* tgt, const float* tvis, const float* denom_dev, float l1w,
+                float bcew, T* dhead) {
+  if (c->dry || nq == 0) return;
+  loss_bwd_kernel<T><<<GRID1D(nq * 4 * T_, 256), 256, 0, c->stream>>>(head, nq, T_, tgt, tvis, denom_dev, l1w, bcew, dhead);
+  SPA_LAUNCH_CHECK(c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimizer: clip_by_global_norm -> adamw -> apply_updates on flat buffers (train.py:239-242)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float lr, float bc1, float bc2, float clip, float b1,
+                                                    float b2, float eps, float wd, float* scratch) {
+  const float gn = sqrtf(scratch[1]);
+  const float sc = gn < clip ? 1.f : clip / gn;
+  if (blockIdx.x == 0 && threadIdx.x == 0) scratch[0] = gn;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float gi = g[i] * sc;
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    float mh = mi / bc1, vh = vi / bc2;
+    float pi = p[i];
+    p[i] = pi - lr * (mh / (sqrtf(vh) + eps) + wd * pi);
+  }
+}
+void k_adamw(spa3d_ctx* c, float* p, const float* g, float* m, float* v, int64_t n, float lr, int64_t step, float clip, float b1, float b2,
+             float eps, float wd, float* scratch) {
+  (void)hipMemsetAsync(scratch, 0, 16, c->stream);
+  unsigned gr = (unsigned)std::min<int64_t>(cdiv(n, 256), 4096);
+  sumsq_kernel<<<gr, 256, 0, c->stream>>>(g, n, scratch + 1);
+  double t = (double)(step + 1);
+  float bc1 = (float)(1.0 - pow((double)b1, t)), bc2 = (float)(1.0 - pow((double)b2, t));
+  adamw_kernel<<<gr, 256, 0, c->stream>>>(p, g, m, v, n, lr, bc1, bc2, clip, b1, b2, eps, wd, scratch);
+  SPA_LAUNCH_CHECK(c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// jax.random.uniform(PRNGKey(k0,k1), [n]) legacy threefry layout
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1) {
+  const uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+  const int R[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+  x0 += ks[0]; x1 += ks[1];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x0 += x1; x1 = rotl32(x1, R[i & 1][j]); x1 ^= x0; }
+    x0 += ks[(i + 1) % 3]; x1 += ks[(i + 2) % 3] + (uint32_t)(i + 1);
+  }
+}
+__global__ void uniform_noise_kernel(float* __restrict__ out, int64_t n, int64_t half, uint32_t k0, uint32_t k1) {
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < half; j += (int64_t)gridDim.x * 256) {
+    uint32_t x0 = (uint32_t)j, x1 = (uint32_t)(half + j);
+    threefry2x32(k0, k1, x0, x1);
+    out[j] = __uint_as_float((x0 >> 9) | 0x3F800000u) - 1.0f;
+    if (half + j < n) out[half + j] = __uint_as_float((x1 >> 9) | 0x3F800000u) - 1.0f;
+  }
+}
+void k_uniform_noise(spa3d_ctx* c, float* out, int64_t n, uint32_t k0, uint32_t k1) {
+  if (c->dry || n == 0) return;
+  int64_t half = (n + (n & 1)) / 2;
+  uniform_noise_kernel<<<GRID1D(half, 256), 256, 0, c->stream>>>(out, n, half, k0, k1); SPA_LAUNCH_CHECK(c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// explicit instantiations
+// ---------------------------------------------------------------------------------------------
+#define INST(T)                                                                                                                        \
+  template void k_layernorm<T>(spa3d_ctx*, const T*, const float*, T*, float*, int64_t, int);                                          \
+  template void k_layernorm_bwd<T>(spa3d_ctx*, const T*, const float*, const float*, const T*, T*, float*, int64_t, int, const T*);    \
+  template void k_rmsnorm_heads<T>(spa3d_ctx*, const T*, int64_t, const float*, T*, int64_t, int64_t, int, int);                       \
+  template void k_rmsnorm_heads_bwd<T>(spa3d_ctx*, const T*, int64_t, const float*, const T*, int64_t, T*, int64_t, float*, int64_t,   \
+                                       int, int);                                                                                     \
+  template void k_softmax<T>(spa3d_ctx*, T*, const float*, int64_t, int, int, int);                                                    \
+  template void k_softmax_bwd<T>(spa3d_ctx*, const T*, T*, int64_t, int);                                                              \
+  template void k_sin_embed<T>(spa3d_ctx*, const float*, int64_t, int, int, float, T*);                                                \
+  template void k_embed_tokens<T>(spa3d_ctx*, const float*, int64_t, int, int, float, T*);                                             \
+  template void k_colsum<T>(spa3d_ctx*, const T*, int64_t, int, int64_t, float*);                                                      \
+  template void k_gelu<T>(spa3d_ctx*, const T*, T*, int64_t);                                                                          \
+  template void k_add<T>(spa3d_ctx*, T*, const T*, int64_t);                                                                           \
+  template void k_cast_from_f32<T>(spa3d_ctx*, const float*, T*, int64_t);                                                             \
+  template void k_cast_to_f32<T>(spa3d_ctx*, const T*, float*, int64_t);                                                               \
+  template void k_pack<T>(spa3d_ctx*, const float*, int64_t, int, int, T*, int64_t, T*, int64_t);                                      \
+  template void k_transpose<T>(spa3d_ctx*, const T*, int, int, T*);                                                                    \
+  template void k_set_readout_rows<T>(spa3d_ctx*, T*, const float*, int64_t, int, int);                                                \
+  template void k_gather_rows<T>(spa3d_ctx*, const T*, int64_t, T*, int64_t, int);                                                     \
+  template void k_scatter_rows<T>(spa3d_ctx*, const T*, T*, int64_t, int64_t, int);                                                    \
+  template void k_compact_tokens<T>(spa3d_ctx*, const T*, T*, int64_t, int, int);                                                      \
+  template void k_broadcast_rows<T>(spa3d_ctx*, const float*, int, int, T*, int64_t);                                                  \
+  template void k_bcast_grad<T>(spa3d_ctx*, const T*, int64_t, int64_t, int64_t, float*);                                              \
+  template void k_assemble_readout<T>(spa3d_ctx*, const T*, const T*, const int32_t*, int64_t, int, int, int, int, T*);                \
+  template void k_assemble_readout_bwd<T>(spa3d_ctx*, const T*, const int32_t*, int64_t, int, int, int, int, T*, float*);              \
+  template void k_loss_bwd<T>(spa3d_ctx*, const float*, int64_t, int, const float*, const float*, const float*, float, float, T*);
+INST(float)
+INST(bf16_t)

@@ -1,0 +1,704 @@
+// model.hip -- host orchestration of the 3DSPA TrackAutoEncoder3D forward / loss / backward on gfx950
+// and the C-ABI of include/spa3d.h.  The graph follows SURVEY.md 0.1 (E1-E7, L1-L3, D1-D8, LOSS) with
+// repairs R2-R5; file:line references are to /root/reference.
+//
+// Memory plan: the batch is processed in chunks of `Bc` samples (every op is per-sample; the only
+// batch-global quantity, the loss denominator, is computed from the targets up front).  Within a chunk
+// all block intermediates needed by the backward are stashed in the caller's workspace (bump arena);
+// parameter gradients accumulate in fp32 across chunks.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+
+#include "common.hpp"
+
+template <typename T>
+void attention_fwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq,
+                   const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, T* o, int impl);
+template <typename T>
+void attention_bwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq,
+                   const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, const T* d_o, T* dq, T* dk, T* dv,
+                   float* dsq, float* dsk, int impl);
+
+static const float L1_WEIGHT = 5000.0f, BCE_WEIGHT = 1e-8f;  // train.py:96
+
+// ---------------------------------------------------------------------------------------------
+// parameter tree: canonical leaf order = sorted Flax paths grouped per module
+// ---------------------------------------------------------------------------------------------
+static void add_leaf(spa3d_ctx* c, const std::string& name, std::initializer_list<int64_t> shape) {
+  Leaf l; l.name = name; l.ndim = (int)shape.size(); int i = 0;
+  for (auto s : shape) l.shape[i++] = s;
+  l.offset = c->nparams;
+  c->nparams += (l.numel() + 63) / 64 * 64;  // 256-B aligned leaves
+  c->leaves.push_back(l);
+}
+static void add_attn(spa3d_ctx* c, const std::string& p, int dq, int dkv) {
+  const int H = c->cfg.num_heads, Dh = c->cfg.qkv_size / H;
+  add_leaf(c, p + "/dense_query/kernel", {dq, H, Dh});
+  add_leaf(c, p + "/dense_key/kernel", {dkv, H, Dh});
+  add_leaf(c, p + "/dense_value/kernel", {dkv, H, Dh});
+  add_leaf(c, p + "/norm_query/scale", {Dh});
+  add_leaf(c, p + "/norm_key/scale", {Dh});
+  add_leaf(c, p + "/dense_out/kernel", {H, Dh, dq});
+  add_leaf(c, p + "/dense_out/bias", {dq});
+}
+static void add_xf(spa3d_ctx* c, const std::string& p, int d, int mlp, int L, int kv) {
+  for (int i = 0; i < L; ++i) {
+    std::string b = p + "/layer_" + std::to_string(i);
+    add_leaf(c, b + "/norm_q/scale", {d});
+    add_attn(c, b + "/self_att", d, d);
+    if (kv) add_attn(c, b + "/cross_att", d, kv);
+    add_leaf(c, b + "/norm_attn/scale", {d});
+    add_leaf(c, b + "/MLP_in/kernel", {d, mlp});
+    add_leaf(c, b + "/MLP_in/bias", {mlp});
+    add_leaf(c, b + "/MLP_out/kernel", {mlp, d});
+    add_leaf(c, b + "/MLP_out/bias", {d});
+  }
+  add_leaf(c, p + "/norm_encoder/scale", {d});
+}
+static void build_leaves(spa3d_ctx* c) {
+  const spa3d_config& g = c->cfg;
+  const int d = g.track_token_dim, dl = g.encoder_latent_dim, dd = g.decoder_num_channels, nf = g.num_frequencies;
+  add_leaf(c, "initializer/state_init", {g.num_latent_tokens, dl});
+  add_leaf(c, "input_readout_token/state_init", {1, d});
+  add_leaf(c, "track_token_projection/kernel", {4 * 2 * nf, d});
+  add_leaf(c, "track_token_projection/bias", {d});
+  if (g.dino_feature_dim > 0) {
+    add_leaf(c, "dino_projection/kernel", {g.dino_feature_dim, d});  // repair R4
+    add_leaf(c, "dino_projection/bias", {d});
+  }
+  if (g.depth_feature_dim > 0) {
+    add_leaf(c, "depth_projection/kernel", {g.depth_feature_dim, d});  // repair R5
+    add_leaf(c, "depth_projection/bias", {d});
+  }
+  add_xf(c, "input_track_transformer", d, g.enc_mlp, g.enc_layers, 0);
+  add_xf(c, "tracks_to_latents", dl, g.t2l_mlp, g.t2l_layers, d);
+  add_leaf(c, "compressor/kernel", {dl, g.latent_token_dim});
+  add_leaf(c, "compressor/bias", {g.latent_token_dim});
+  add_leaf(c, "decompressor/kernel", {g.latent_token_dim, dd - 128});
+  add_leaf(c, "decompressor/bias", {dd - 128});
+  add_xf(c, "decompress_attn", dd - 128, g.dec_mlp, g.dec_layers, 0);
+  add_xf(c, "track_readout_attn", dd, g.ro_mlp, g.ro_layers, 0);
+  const int qin = (3 * 2 * nf + 1) * 2 * nf;
+  add_leaf(c, "query_encoder/kernel", {qin, dd});
+  add_leaf(c, "query_encoder/bias", {dd});
+  add_leaf(c, "track_predictor/kernel", {dd, 4 * g.num_output_frames});
+  add_leaf(c, "track_predictor/bias", {4 * g.num_output_frames});
+}
+
+// ---------------------------------------------------------------------------------------------
+// weights as the kernels want them
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Lin {
+  T* wn = nullptr;            // [K][N]  (dX = dY . wn^T reads it K'-contiguous)
+  T* wt = nullptr;            // [N][K]  (Y = X . W with K contiguous)
+  const float* bias = nullptr;
+  int K = 0, N = 0, nseg = 1, segw = 0;
+  const float* src[3] = {nullptr, nullptr, nullptr};  // f32 leaves [K][segw]
+  float* gw[3] = {nullptr, nullptr, nullptr};         // f32 grads  [K][segw]
+  float* gb = nullptr;
+};
+template <typename T> struct BlockW {
+  int d = 0, mlp = 0, dkv = 0; bool cross = false;
+  const float *norm_q, *norm_attn, *sq, *sk, *csq = nullptr, *csk = nullptr;
+  float *g_norm_q, *g_norm_attn, *g_sq, *g_sk, *g_csq = nullptr, *g_csk = nullptr;
+  Lin<T> qkv, out, cq, ckv, cout, mlp_in, mlp_out;
+};
+template <typename T> struct XfW { std::vector<BlockW<T>> blocks; const float* norm_enc; float* g_norm_enc; int d; };
+template <typename T> struct BlockStash {
+  T *x, *nq, *qkv, *o, *a, *na, *hpre, *cq = nullptr, *ckv = nullptr, *co = nullptr;
+  float *st1, *st2;
+};
+
+template <typename T> struct Net {
+  spa3d_ctx* c; const spa3d_config& g; const float* P; float* G;
+  std::map<std::string, int64_t> off;
+  int H, Dh, E;
+  Lin<T> tok, dino, depth, comp, decomp, qenc, pred;
+  XfW<T> enc, t2l, dec, ro;
+  const float *lat0, *readout; float *g_lat0, *g_readout;
+
+  Net(spa3d_ctx* c_, const float* P_, float* G_) : c(c_), g(c_->cfg), P(P_), G(G_) {
+    for (auto& l : c->leaves) off[l.name] = l.offset;
+    H = g.num_heads; Dh = g.qkv_size / H; E = g.qkv_size;
+  }
+  template <typename U> U* alloc(int64_t n) { return (U*)c->ar.alloc(n * (int64_t)sizeof(U)); }
+  const float* p(const std::string& n) { return P + off.at(n); }
+  float* gr(const std::string& n) { return G ? G + off.at(n) : nullptr; }
+
+  Lin<T> make_lin(std::initializer_list<std::string> kernels, const std::string& bias, int K, int segw) {
+    Lin<T> l; l.K = K; l.segw = segw; l.nseg = (int)kernels.size(); l.N = segw * l.nseg;
+    int i = 0;
+    for (auto& k : kernels) { l.src[i] = p(k); l.gw[i] = gr(k); ++i; }
+    if (!bias.empty()) { l.bias = p(bias); l.gb = gr(bias); }
+    l.wn = alloc<T>((int64_t)K * l.N); l.wt = alloc<T>((int64_t)K * l.N);
+    for (int s = 0; s < l.nseg; ++s)
+      k_pack<T>(c, l.src[s], segw, K, segw, l.wn + (int64_t)s * segw, l.N, l.wt + (int64_t)s * segw * K, K);
+    return l;
+  }
+  XfW<T> make_xf(const std::string& name, int d, int mlp, int L, int kv) {
+    XfW<T> x; x.d = d;
+    for (int i = 0; i < L; ++i) {
+      std::string b = name + "/layer_" + std::to_string(i);
+      BlockW<T> w; w.d = d; w.mlp = mlp; w.cross = kv > 0; w.dkv = kv;
+      w.norm_q = p(b + "/norm_q/scale"); w.g_norm_q = gr(b + "/norm_q/scale");
+      w.norm_attn = p(b + "/norm_attn/scale"); w.g_norm_attn = gr(b + "/norm_attn/scale");
+      std::string s = b + "/self_att";
+      w.qkv = make_lin({s + "/dense_query/kernel", s + "/dense_key/kernel", s + "/dense_value/kernel"}, "", d, E);
+      w.sq = p(s + "/norm_query/scale"); w.g_sq = gr(s + "/norm_query/scale");
+      w.sk = p(s + "/norm_key/scale"); w.g_sk = gr(s + "/norm_key/scale");
+      w.out = make_lin({s + "/dense_out/kernel"}, s + "/dense_out/bias", E, d);
+      if (kv) {
+        std::string x2 = b + "/cross_att";
+        w.cq = make_lin({x2 + "/dense_query/kernel"}, "", d, E);
+        w.ckv = make_lin({x2 + "/dense_key/kernel", x2 + "/dense_value/kernel"}, "", kv, E);
+        w.csq = p(x2 + "/norm_query/scale"); w.g_csq = gr(x2 + "/norm_query/scale");
+        w.csk = p(x2 + "/norm_key/scale"); w.g_csk = gr(x2 + "/norm_key/scale");
+        w.cout = make_lin({x2 + "/dense_out/kernel"}, x2 + "/dense_out/bias", E, d);
+      }
+      w.mlp_in = make_lin({b + "/MLP_in/kernel"}, b + "/MLP_in/bias", d, mlp);
+      w.mlp_out = make_lin({b + "/MLP_out/kernel"}, b + "/MLP_out/bias", mlp, d);
+      x.blocks.push_back(w);
+    }
+    x.norm_enc = p(name + "/norm_encoder/scale"); x.g_norm_enc = gr(name + "/norm_encoder/scale");
+    return x;
+  }
+  // builds all shadows at the current arena position (re-done every call: 0.9 GB of traffic, << 1 ms)
+  void pack() {
+    const int d = g.track_token_dim, dl = g.encoder_latent_dim, dd = g.decoder_num_channels, nf = g.num_frequencies;
+    lat0 = p("initializer/state_init"); g_lat0 = gr("initializer/state_init");
+    readout = p("input_readout_token/state_init"); g_readout = gr("input_readout_token/state_init");
+    tok = make_lin({"track_token_projection/kernel"}, "track_token_projection/bias", 8 * nf, d);
+    if (g.dino_feature_dim > 0) dino = make_lin({"dino_projection/kernel"}, "dino_projection/bias", g.dino_feature_dim, d);
+    if (g.depth_feature_dim > 0) depth = make_lin({"depth_projection/kernel"}, "depth_projection/bias", g.depth_feature_dim, d);
+    enc = make_xf("input_track_transformer", d, g.enc_mlp, g.enc_layers, 0);
+    t2l = make_xf("tracks_to_latents", dl, g.t2l_mlp, g.t2l_layers, d);
+    comp = make_lin({"compressor/kernel"}, "compressor/bias", dl, g.latent_token_dim);
+    decomp = make_lin({"decompressor/kernel"}, "decompressor/bias", g.latent_token_dim, dd - 128);
+    dec = make_xf("decompress_attn", dd - 128, g.dec_mlp, g.dec_layers, 0);
+    ro = make_xf("track_readout_attn", dd, g.ro_mlp, g.ro_layers, 0);
+    qenc = make_lin({"query_encoder/kernel"}, "query_encoder/bias", (6 * nf + 1) * 2 * nf, dd);
+    pred = make_lin({"track_predictor/kernel"}, "track_predictor/bias", dd, 4 * g.num_output_frames);
+  }
+
+  // ------------------------------------------------------------------ GEMM front ends
+  void gemm(const GemmDesc& d) {
+    if constexpr (sizeof(T) == 2) {
+      if (c->gemm_impl != 1) {
+        if (gemm_nt_bf16(c, d)) return;
+        if (gemm_tn_bf16(c, d)) return;
+      }
+    }
+    gemm_generic<T>(c, d);
+  }
+  // Y[M,N] = epi(X[M,K] W + b) (+ residual)
+  void lin_fwd(const Lin<T>& l, const T* X, void* Y, int64_t M, int epi = EPI_NONE, const T* residual = nullptr, int out_f32 = 0,
+               int accumulate = 0, int64_t ldx = 0, int64_t ldy = 0, int nb = 1, int64_t bX = 0, int64_t bY = 0) {
+    GemmDesc d{};
+    d.A = X; d.B = l.wn; d.C = Y; d.M = M; d.N = l.N; d.K = l.K;
+    d.sAm = ldx ? ldx : l.K; d.sAk = 1; d.sBk = l.N; d.sBn = 1; d.sCm = ldy ? ldy : l.N;
+    d.Bt = l.wt; d.ldBt = l.K;
+    d.nb1 = nb; d.bA1 = bX; d.bC1 = bY;
+    d.bias = l.bias; d.epi = epi; d.aux = residual; d.out_f32 = out_f32; d.accumulate = accumulate;
+    gemm(d);
+  }
+  // dX[M,K] (op)= dY[M,N] W^T, optionally * gelu'(pre)
+  void lin_bwd_x(const Lin<T>& l, const T* dY, T* dX, int64_t M, const T* gelu_pre = nullptr, int accumulate = 0) {
+    GemmDesc d{};
+    d.A = dY; d.B = l.wn; d.C = dX; d.M = M; d.N = l.K; d.K = l.N;
+    d.sAm = l.N; d.sAk = 1; d.sBk = 1; d.sBn = l.N; d.sCm = l.K;
+    d.Bt = l.wn; d.ldBt = l.N;
+    if (gelu_pre) { d.epi = EPI_MUL_GELU_GRAD; d.aux = gelu_pre; }
+    d.accumulate = accumulate;
+    gemm(d);
+  }
+  // gw += X^T dY ; gb += colsum(dY)
+  void lin_bwd_w(const Lin<T>& l, const T* X, const T* dY, int64_t M, int64_t ldx = 0) {
+    for (int s = 0; s < l.nseg; ++s) {
+      GemmDesc d{};
+      d.A = X; d.B = dY + (int64_t)s * l.segw; d.C = l.gw[s]; d.M = l.K; d.N = l.segw; d.K = M;
+      d.sAm = 1; d.sAk = ldx ? ldx : l.K; d.sBk = l.N; d.sBn = 1; d.sCm = l.segw;
+      d.out_f32 = 1; d.accumulate = 1;
+      gemm(d);
+    }
+    if (l.gb) k_colsum<T>(c, dY, M, l.N, l.N, l.gb);
+  }
+
+  // ------------------------------------------------------------------ attention core (attention.hip)
+  void attn_fwd(const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq, const float* sk,
+                const float* km, int64_t nseq, int Sq, int Sk, T* o) {
+    attention_fwd<T>(c, q, k, v, ldq, ldk, ldv, sq, sk, km, nseq, Sq, Sk, H, Dh, o, c->attn_impl);
+  }
+  void attn_bwd(const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq, const float* sk,
+                const float* km, int64_t nseq, int Sq, int Sk, const T* d_o, T* dq, T* dk, T* dv, float* dsq, float* dsk) {
+    attention_bwd<T>(c, q, k, v, ldq, ldk, ldv, sq, sk, km, nseq, Sq, Sk, H, Dh, d_o, dq, dk, dv, dsq, dsk, c->attn_impl);
+  }
+
+  // ------------------------------------------------------------------ ImprovedTransformerBlock (attention.py:67-108)
+  void block_fwd(const BlockW<T>& w, const T* x, T* y, int64_t nseq, int S, const float* km, const T* kv, int Skv, BlockStash<T>* st) {
+    const int64_t M = nseq * S; const int d = w.d;
+    int64_t mk = c->ar.mark();
+    T* nq = alloc<T>(M * d); float* st1 = alloc<float>(M * 2);
+    k_layernorm<T>(c, x, w.norm_q, nq, st1, M, d);                                      // :76-78
+    T* qkv = alloc<T>(M * 3 * E);
+    lin_fwd(w.qkv, nq, qkv, M);                                                         // :154-173
+    T* o = alloc<T>(M * E);
+    attn_fwd(qkv, qkv + E, qkv + 2 * E, 3 * E, 3 * E, 3 * E, w.sq, w.sk, km, nseq, S, S, o);  // :166-175
+    T* a = alloc<T>(M * d);
+    lin_fwd(w.out, o, a, M, EPI_NONE, x);                                               // :178-183 + residual :79,90
+    T *cq = nullptr, *ckv = nullptr, *co = nullptr;
+    if (w.cross) {                                                                      // :92-100
+      cq = alloc<T>(M * E); lin_fwd(w.cq, nq, cq, M);
+      ckv = alloc<T>(nseq * Skv * 2 * E); lin_fwd(w.ckv, kv, ckv, nseq * Skv);
+      co = alloc<T>(M * E);
+      attn_fwd(cq, ckv, ckv + E, E, 2 * E, 2 * E, w.csq, w.csk, nullptr, nseq, S, Skv, co);
+      lin_fwd(w.cout, co, a, M, EPI_NONE, a);
+    }
+    T* na = alloc<T>(M * d); float* st2 = alloc<float>(M * 2);
+    k_layernorm<T>(c, a, w.norm_attn, na, st2, M, d);                                   // :103-105
+    T* hpre = alloc<T>(M * w.mlp);
+    lin_fwd(w.mlp_in, na, hpre, M);                                                     // :106
+    int64_t mk2 = c->ar.mark();
+    T* h = alloc<T>(M * w.mlp);
+    k_gelu<T>(c, hpre, h, M * w.mlp);
+    lin_fwd(w.mlp_out, h, y, M, EPI_NONE, a);                                           // :107-108
+    c->ar.release(mk2);
+    if (st) { st->x = const_cast<T*>(x); st->nq = nq; st->qkv = qkv; st->o = o; st->a = a; st->na = na; st->hpre = hpre;
+              st->st1 = st1; st->st2 = st2; st->cq = cq; st->ckv = ckv; st->co = co; }
+    else c->ar.release(mk);
+  }
+  // dy -> dx (dx may alias dy); dkv accumulated (T) if cross
+  void block_bwd(const BlockW<T>& w, const BlockStash<T>& s, const T* dy, T* dx, int64_t nseq, int S, const float* km, const T* kv,
+                 int Skv, T* dkv) {
+    const int64_t M = nseq * S; const int d = w.d;
+    int64_t mk = c->ar.mark();
+    T* h = alloc<T>(M * w.mlp);
+    k_gelu<T>(c, s.hpre, h, M * w.mlp);
+    lin_bwd_w(w.mlp_out, h, dy, M);
+    T* dh = h;  // reuse: dh = dy Wout^T * gelu'(hpre)
+    lin_bwd_x(w.mlp_out, dy, dh, M, s.hpre);
+    lin_bwd_w(w.mlp_in, s.na, dh, M);
+    T* dna = alloc<T>(M * d);
+    lin_bwd_x(w.mlp_in, dh, dna, M);
+    T* da = alloc<T>(M * d);
+    k_layernorm_bwd<T>(c, s.a, w.norm_attn, s.st2, dna, da, w.g_norm_attn, M, d, dy);  // da = dy + LNbwd
+    T* dnq = dna;  // reuse
+    // self attention
+    lin_bwd_w(w.out, s.o, da, M);
+    T* d_o = alloc<T>(M * E);
+    lin_bwd_x(w.out, da, d_o, M);
+    T* dqkv = alloc<T>(M * 3 * E);
+    attn_bwd(s.qkv, s.qkv + E, s.qkv + 2 * E, 3 * E, 3 * E, 3 * E, w.sq, w.sk, km, nseq, S, S, d_o, dqkv, dqkv + E, dqkv + 2 * E,
+             w.g_sq, w.g_sk);
+    lin_bwd_w(w.qkv, s.nq, dqkv, M);
+    lin_bwd_x(w.qkv, dqkv, dnq, M);
+    if (w.cross) {
+      lin_bwd_w(w.cout, s.co, da, M);
+      lin_bwd_x(w.cout, da, d_o, M);  // d_o := d co
+      T* dcq = dqkv;                  // reuse [M,E]
+      T* dckv = alloc<T>(nseq * Skv * 2 * E);
+      attn_bwd(s.cq, s.ckv, s.ckv + E, E, 2 * E, 2 * E, w.csq, w.csk, nullptr, nseq, S, Skv, d_o, dcq, dckv, dckv + E, w.g_csq, w.g_csk);
+      // attn_bwd writes dq with stride ldq = E into dcq: dense [M,E]
+      lin_bwd_w(w.cq, s.nq, dcq, M);
+      lin_bwd_x(w.cq, dcq, dnq, M, nullptr, 1);
+      lin_bwd_w(w.ckv, kv, dckv, nseq * Skv);
+      lin_bwd_x(w.ckv, dckv, dkv, nseq * Skv, nullptr, 1);
+    }
+    k_layernorm_bwd<T>(c, s.x, w.norm_q, s.st1, dnq, dx, w.g_norm_q, M, d, da);  // dx = da + LNbwd
+    c->ar.release(mk);
+  }
+
+  // ------------------------------------------------------------------ per-chunk state
+  struct Chunk {
+    int64_t Bc, nseq; int N, Q, T_, S;
+    // encoder
+    T* sinbuf; const void* dino; const void* depthf; float* km; T* tok0; std::vector<BlockStash<T>> enc_st; T* enc_last; T* r0; float* st_r0;
+    T* enc_out;
+    // t2l
+    T* lat_in; std::vector<BlockStash<T>> t2l_st; T* t2l_last; float* st_t2l; T* t2l_n; float* latents;  // [Bc,L,Ld] f32
+    // decode
+    float* clipmask; float* lat_q; T* lat_qT; T* dec_in; std::vector<BlockStash<T>> dec_st; T* dec_last; float* st_dec; T* latd;
+    float* feat; int32_t* qframe; T* sin2; T* qtok; T* seq0; std::vector<BlockStash<T>> ro_st; T* ro_last; T* q0; float* st_q0; T* q0n;
+    float* head;
+  };
+
+  // E1-E7 + L1-L3 (track_autoencoder_3d.py:123-204)
+  void encode_chunk(Chunk& k, const spa3d_batch* b, int64_t b0, bool train) {
+    const int d = g.track_token_dim, nf = g.num_frequencies, T_ = k.T_, S = k.S;
+    const int64_t nseq = k.nseq;
+    const float* tracks = b->support_tracks + b0 * k.N * T_ * 3;
+    k.sinbuf = alloc<T>(nseq * T_ * 8 * nf);
+    k_embed_tokens<T>(c, tracks, nseq * T_, T_, nf, g.track_scale_factor, k.sinbuf);                 // 3d:126-134
+    k.tok0 = alloc<T>(nseq * S * d);
+    // rows 1..T of every sequence <- Dense(sin) [+ Dense(dino)] [+ Dense(depth)]                      3d:137-147
+    lin_fwd(tok, k.sinbuf, k.tok0 + d, T_, EPI_NONE, nullptr, 0, 0, 0, 0, (int)nseq, (int64_t)T_ * tok.K, (int64_t)S * d);
+    k.dino = nullptr; k.depthf = nullptr;
+    if (g.dino_feature_dim > 0 && b->dino_features) {
+      k.dino = (const T*)b->dino_features + b0 * k.N * T_ * g.dino_feature_dim;
+      lin_fwd(dino, (const T*)k.dino, k.tok0 + d, T_, EPI_NONE, nullptr, 0, 1, 0, 0, (int)nseq, (int64_t)T_ * dino.K, (int64_t)S * d);
+    }
+    if (g.depth_feature_dim > 0 && b->depth_features) {
+      k.depthf = (const T*)b->depth_features + b0 * k.N * T_ * g.depth_feature_dim;
+      lin_fwd(depth, (const T*)k.depthf, k.tok0 + d, T_, EPI_NONE, nullptr, 0, 1, 0, 0, (int)nseq, (int64_t)T_ * depth.K, (int64_t)S * d);
+    }
+    k_set_readout_rows<T>(c, k.tok0, readout, nseq, S, d);                                           // 3d:161-165
+    k.km = alloc<float>(nseq * S);
+    k_keymask(c, b->support_tracks_visible + b0 * k.N * T_, b->boundary_frame + b0, nseq, k.N, T_, k.km);  // 3d:167-180 (R2,R3)
+    const T* x = k.tok0;
+    k.enc_st.resize(enc.blocks.size());
+    T* pp[2] = {nullptr, nullptr};
+    if (!train) { pp[0] = alloc<T>(nseq * S * d); pp[1] = alloc<T>(nseq * S * d); }
+    for (size_t i = 0; i < enc.blocks.size(); ++i) {
+      T* y = train ? alloc<T>(nseq * S * d) : pp[i & 1];
+      block_fwd(enc.blocks[i], x, y, nseq, S, k.km, nullptr, 0, train ? &k.enc_st[i] : nullptr);
+      x = y;
+    }
+    k.enc_last = const_cast<T*>(x);
+    k.r0 = alloc<T>(nseq * d); k.st_r0 = alloc<float>(nseq * 2); k.enc_out = alloc<T>(nseq * d);
+    k_gather_rows<T>(c, x, S, k.r0, nseq, d);                                                        // 3d:187-188
+    k_layernorm<T>(c, k.r0, enc.norm_enc, k.enc_out, k.st_r0, nseq, d);                              // attention.py:49-51 (row 0 only)
+    // L1-L3
+    const int L = g.num_latent_tokens, dl = g.encoder_latent_dim;
+    k.lat_in = alloc<T>(k.Bc * L * dl);
+    k_broadcast_rows<T>(c, lat0, L, dl, k.lat_in, k.Bc);                                             // 3d:200
+    x = k.lat_in;
+    k.t2l_st.resize(t2l.blocks.size());
+    for (size_t i = 0; i < t2l.blocks.size(); ++i) {
+      T* y = alloc<T>(k.Bc * L * dl);
+      block_fwd(t2l.blocks[i], x, y, k.Bc, L, nullptr, k.enc_out, k.N, train ? &k.t2l_st[i] : nullptr);  // 3d:201
+      x = y;
+    }
+    k.t2l_last = const_cast<T*>(x);
+    k.st_t2l = alloc<float>(k.Bc * L * 2); k.t2l_n = alloc<T>(k.Bc * L * dl);
+    k_layernorm<T>(c, x, t2l.norm_enc, k.t2l_n, k.st_t2l, k.Bc * L, dl);
+    k.latents = alloc<float>(k.Bc * L * g.latent_token_dim);
+    lin_fwd(comp, k.t2l_n, k.latents, k.Bc * L, EPI_NONE, nullptr, 1);                               // 3d:203
+  }
+
+  // D1-D8 (track_autoencoder_3d.py:206-307).  latents_in: [Bc,L,Ld] f32
+  void decode_chunk(Chunk& k, const spa3d_batch* b, int64_t b0, const float* latents_in, const float* noise, bool train) {
+    const int L = g.num_latent_tokens, Ld = g.latent_token_dim, dd = g.decoder_num_channels, Cl = dd - 128, nf = g.num_frequencies;
+    const int64_t nl = k.Bc * L, nq = k.Bc * k.Q;
+    k.clipmask = alloc<float>(nl * Ld); k.lat_q = alloc<float>(nl * Ld); k.lat_qT = alloc<T>(nl * Ld);
+    k_discretize(c, latents_in, noise ? noise + b0 * L * Ld : nullptr, b->discretize, k.lat_q, k.clipmask, nl * Ld);  // 3d:251-260
+    k_cast_from_f32<T>(c, k.lat_q, k.lat_qT, nl * Ld);
+    k.dec_in = alloc<T>(nl * Cl);
+    lin_fwd(decomp, k.lat_qT, k.dec_in, nl);                                                         // 3d:262
+    const T* x = k.dec_in;
+    k.dec_st.resize(dec.blocks.size());
+    for (size_t i = 0; i < dec.blocks.size(); ++i) {
+      T* y = alloc<T>(nl * Cl);
+      block_fwd(dec.blocks[i], x, y, k.Bc, L, nullptr, nullptr, 0, train ? &k.dec_st[i] : nullptr);  // 3d:263
+      x = y;
+    }
+    k.dec_last = const_cast<T*>(x);
+    k.st_dec = alloc<float>(nl * 2); k.latd = alloc<T>(nl * Cl);
+    k_layernorm<T>(c, x, dec.norm_enc, k.latd, k.st_dec, nl, Cl);
+    // query tokens                                                                                     3d:209-233,265-275
+    const int F = 6 * nf + 1;
+    k.feat = alloc<float>(nq * F); k.qframe = alloc<int32_t>(nq);
+    k_query_embed1(c, b->query_points + b0 * k.Q * 4, nq, nf, g.track_scale_factor, g.time_scale_factor, k.feat, k.qframe);
+    k.sin2 = alloc<T>(nq * F * 2 * nf);
+    k_sin_embed<T>(c, k.feat, nq, F, nf, g.track_scale_factor, k.sin2);
+    k.qtok = alloc<T>(nq * dd);
+    lin_fwd(qenc, k.sin2, k.qtok, nq);
+    // readout sequences                                                                                3d:276-285
+    const int S = L + 1;
+    k.seq0 = alloc<T>(nq * S * dd);
+    k_assemble_readout<T>(c, k.qtok, k.latd, k.qframe, k.Bc, k.Q, L, Cl, dd, k.seq0);
+    x = k.seq0;
+    k.ro_st.resize(ro.blocks.size());
+    T* pp[2] = {nullptr, nullptr};
+    if (!train) { pp[0] = alloc<T>(nq * S * dd); pp[1] = alloc<T>(nq * S * dd); }
+    for (size_t i = 0; i < ro.blocks.size(); ++i) {
+      T* y = train ? alloc<T>(nq * S * dd) : pp[i & 1];
+      block_fwd(ro.blocks[i], x, y, nq, S, nullptr, nullptr, 0, train ? &k.ro_st[i] : nullptr);
+      x = y;
+    }
+    k.ro_last = const_cast<T*>(x);
+    k.q0 = alloc<T>(nq * dd); k.st_q0 = alloc<float>(nq * 2); k.q0n = alloc<T>(nq * dd);
+    k_gather_rows<T>(c, x, S, k.q0, nq, dd);                                                          // 3d:286
+    k_layernorm<T>(c, k.q0, ro.norm_enc, k.q0n, k.st_q0, nq, dd);
+    k.head = alloc<float>(nq * 4 * g.num_output_frames);
+    lin_fwd(pred, k.q0n, k.head, nq, EPI_NONE, nullptr, 1);                                           // 3d:287
+  }
+
+
+  // full backward of one chunk; parameter gradients accumulate into G
+  void backward_chunk(Chunk& k, const spa3d_batch* b, int64_t b0, const float* denom_dev) {
+    const int L = g.num_latent_tokens, Ld = g.latent_token_dim, dd = g.decoder_num_channels, Cl = dd - 128, To = g.num_output_frames;
+    const int d = g.track_token_dim, dl = g.encoder_latent_dim, T_ = k.T_;
+    const int64_t nl = k.Bc * L, nq = k.Bc * k.Q, nseq = k.nseq;
+    const int64_t mk0 = c->ar.mark();
+    float* dlatd32 = alloc<float>(nl * Cl);
+    {  // ---- head, readout transformer, assembly, query encoder
+      const int S = L + 1;
+      const int64_t mk = c->ar.mark();
+      T* dhead = alloc<T>(nq * 4 * To);
+      k_loss_bwd<T>(c, k.head, nq, To, b->query_tracks + b0 * k.Q * To * 3, b->query_tracks_visible + b0 * k.Q * To, denom_dev,
+                    L1_WEIGHT, BCE_WEIGHT, dhead);
+      lin_bwd_w(pred, k.q0n, dhead, nq);
+      T* dq0n = alloc<T>(nq * dd);
+      lin_bwd_x(pred, dhead, dq0n, nq);
+      T* dq0 = alloc<T>(nq * dd);
+      k_layernorm_bwd<T>(c, k.q0, ro.norm_enc, k.st_q0, dq0n, dq0, ro.g_norm_enc, nq, dd, nullptr);
+      T* dqtok = alloc<T>(nq * dd);
+      T* dseq = alloc<T>(nq * S * dd);
+      k_zero(c, dseq, nq * S * dd * (int64_t)sizeof(T));  // only token 0 leaves the readout stack (3d:286)
+      k_scatter_rows<T>(c, dq0, dseq, S, nq, dd);
+      for (int i = (int)ro.blocks.size() - 1; i >= 0; --i)
+        block_bwd(ro.blocks[i], k.ro_st[i], dseq, dseq, nq, S, nullptr, nullptr, 0, nullptr);
+      k_assemble_readout_bwd<T>(c, dseq, k.qframe, k.Bc, k.Q, L, Cl, dd, dqtok, dlatd32);
+      lin_bwd_w(qenc, k.sin2, dqtok, nq);
+      c->ar.release(mk);
+    }
+    // ---- decompress_attn, decompressor, straight-through clip, compressor
+    T* ddec = alloc<T>(nl * Cl);
+    {
+      T* dlatd = alloc<T>(nl * Cl);
+      k_cast_from_f32<T>(c, dlatd32, dlatd, nl * Cl);
+      k_layernorm_bwd<T>(c, k.dec_last, dec.norm_enc, k.st_dec, dlatd, ddec, dec.g_norm_enc, nl, Cl, nullptr);
+    }
+    for (int i = (int)dec.blocks.size() - 1; i >= 0; --i)
+      block_bwd(dec.blocks[i], k.dec_st[i], ddec, ddec, k.Bc, L, nullptr, nullptr, 0, nullptr);
+    lin_bwd_w(decomp, k.lat_qT, ddec, nl);
+    T* dlq = alloc<T>(nl * Ld);
+    lin_bwd_x(decomp, ddec, dlq, nl);
+    float* dl32 = alloc<float>(nl * Ld);
+    k_cast_to_f32<T>(c, dlq, dl32, nl * Ld);
+    k_mul(c, dl32, k.clipmask, nl * Ld);  // d/dl [l - stop_grad(l - q)] = 1, times the clip mask (3d:251,260)
+    k_cast_from_f32<T>(c, dl32, dlq, nl * Ld);
+    lin_bwd_w(comp, k.t2l_n, dlq, nl);
+    T* dt2ln = alloc<T>(nl * dl);
+    lin_bwd_x(comp, dlq, dt2ln, nl);
+    T* dt2l = alloc<T>(nl * dl);
+    k_layernorm_bwd<T>(c, k.t2l_last, t2l.norm_enc, k.st_t2l, dt2ln, dt2l, t2l.g_norm_enc, nl, dl, nullptr);
+    T* denc_out = alloc<T>(nseq * d);
+    k_zero(c, denc_out, nseq * d * (int64_t)sizeof(T));
+    for (int i = (int)t2l.blocks.size() - 1; i >= 0; --i)
+      block_bwd(t2l.blocks[i], k.t2l_st[i], dt2l, dt2l, k.Bc, L, nullptr, k.enc_out, k.N, denc_out);
+    k_bcast_grad<T>(c, dt2l, (int64_t)L * dl, k.Bc, (int64_t)L * dl, g_lat0);
+    // ---- track encoder
+    const int S = k.S;
+    T* dr0 = alloc<T>(nseq * d);
+    k_layernorm_bwd<T>(c, k.r0, enc.norm_enc, k.st_r0, denc_out, dr0, enc.g_norm_enc, nseq, d, nullptr);
+    T* dtok = alloc<T>(nseq * S * d);
+    k_zero(c, dtok, nseq * S * d * (int64_t)sizeof(T));  // only the readout token leaves the stack (3d:187-188)
+    k_scatter_rows<T>(c, dr0, dtok, S, nseq, d);
+    for (int i = (int)enc.blocks.size() - 1; i >= 0; --i)
+      block_bwd(enc.blocks[i], k.enc_st[i], dtok, dtok, nseq, S, k.km, nullptr, 0, nullptr);
+    k_bcast_grad<T>(c, dtok, d, nseq, (int64_t)S * d, g_readout);
+    T* dtokc = alloc<T>(nseq * T_ * d);
+    k_compact_tokens<T>(c, dtok, dtokc, nseq, S, d);
+    lin_bwd_w(tok, k.sinbuf, dtokc, nseq * T_);
+    if (k.dino) lin_bwd_w(dino, (const T*)k.dino, dtokc, nseq * T_);
+    if (k.depthf) lin_bwd_w(depth, (const T*)k.depthf, dtokc, nseq * T_);
+    c->ar.release(mk0);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// drivers
+// ---------------------------------------------------------------------------------------------
+enum { MODE_FORWARD = 0, MODE_TRAIN = 1, MODE_ENCODE = 2, MODE_DECODE = 3 };
+
+struct RunArgs {
+  int mode; const float* P; const spa3d_batch* b; float denom; float* G; int accumulate; float* loss3; spa3d_outputs* out;
+  const float* latents_in; float* latents_out; int chunk;  // chunk: fixed Bc (>0) or 0 = as large as fits
+};
+
+template <typename T>
+static void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
+  const spa3d_config& g = c->cfg; const spa3d_batch* b = a.b;
+  const int L = g.num_latent_tokens, Ld = g.latent_token_dim, To = g.num_output_frames;
+  const bool train = a.mode == MODE_TRAIN;
+  Net<T> net(c, a.P, a.G);
+  net.pack();
+  float* sums = net.template alloc<float>(8);
+  float* denom_dev = sums + 4;
+  k_zero(c, sums, 32);
+  const float* noise = b->noise;
+  if (a.mode != MODE_ENCODE && b->discretize && !noise) {
+    float* nb = net.template alloc<float>((int64_t)b->B * L * Ld);
+    k_uniform_noise(c, nb, (int64_t)b->B * L * Ld, 0u, 0u);  // PRNGKey(0), 3d:254
+    noise = nb;
+  }
+  if (train) {
+    k_vis_count(c, b->query_tracks_visible, (int64_t)b->B * b->Q * To, sums + 2);
+    k_set_denom(c, sums, a.denom, denom_dev);
+    if (!a.accumulate) k_zero(c, a.G, c->nparams * 4);
+  }
+  for (int64_t b0 = 0; b0 < b->B; b0 += Bc) {
+    typename Net<T>::Chunk k{};
+    k.Bc = std::min<int64_t>(Bc, b->B - b0); k.N = b->N; k.Q = b->Q; k.T_ = b->T; k.S = b->T + 1; k.nseq = k.Bc * b->N;
+    const int64_t mk = c->ar.mark();
+    const float* lat = nullptr;
+    if (a.mode != MODE_DECODE) {
+      net.encode_chunk(k, b, b0, train);
+      lat = k.latents;
+      float* lo = a.latents_out ? a.latents_out : (a.out && a.out->latents ? a.out->latents : nullptr);
+      if (lo && !c->dry) (void)hipMemcpyAsync(lo + b0 * L * Ld, k.latents, k.Bc * L * Ld * 4, hipMemcpyDeviceToDevice, c->stream);
+    } else {
+      lat = a.latents_in + b0 * L * Ld;
+    }
+    if (a.mode != MODE_ENCODE) {
+      net.decode_chunk(k, b, b0, lat, noise, train);
+      const int64_t nq = k.Bc * k.Q;
+      float* tr = a.out && a.out->tracks ? a.out->tracks + b0 * b->Q * To * 3 : nullptr;
+      float* vl = a.out && a.out->visible_logits ? a.out->visible_logits + b0 * b->Q * To : nullptr;
+      float* cl = a.out && a.out->certain_logits ? a.out->certain_logits + b0 * b->Q * To : nullptr;
+      k_loss_fwd(c, k.head, nq, To, train ? b->query_tracks + b0 * b->Q * To * 3 : nullptr,
+                 train ? b->query_tracks_visible + b0 * b->Q * To : nullptr, tr, vl, cl, sums);
+      if (train) net.backward_chunk(k, b, b0, denom_dev);
+    }
+    c->ar.release(mk);
+  }
+  if (train && a.loss3) k_loss_finalize(c, sums, denom_dev, L1_WEIGHT, BCE_WEIGHT, a.loss3);
+}
+
+static void run_dispatch(spa3d_ctx* c, const RunArgs& a, int Bc) {
+  if (c->cfg.precision == SPA3D_F32) run_body<float>(c, a, Bc); else run_body<bf16_t>(c, a, Bc);
+}
+
+static int64_t dry_need(spa3d_ctx* c, const RunArgs& a, int Bc) {
+  Arena saved = c->ar; bool sd = c->dry;
+  c->ar = Arena(); c->ar.dry = true; c->dry = true;
+  RunArgs d = a; d.P = (const float*)0x100000; d.G = a.G ? (float*)0x100000 : nullptr;
+  run_dispatch(c, d, Bc);
+  int64_t need = c->ar.peak + 4096;
+  c->ar = saved; c->dry = sd;
+  return need;
+}
+
+static int check_batch(spa3d_ctx* c, const spa3d_batch* b, int mode) {
+  if (!b || b->B <= 0 || b->Q <= 0) { c->err = "batch: B,Q must be positive"; return SPA3D_ERR_ARG; }
+  if (mode != MODE_DECODE && (b->N <= 0 || b->T <= 0 || !b->support_tracks || !b->support_tracks_visible || !b->boundary_frame)) {
+    c->err = "batch: support_tracks / support_tracks_visible / boundary_frame required"; return SPA3D_ERR_ARG;
+  }
+  if (mode != MODE_ENCODE && !b->query_points) { c->err = "batch: query_points required (host builds the default grid)"; return SPA3D_ERR_ARG; }
+  if (mode == MODE_TRAIN && (!b->query_tracks || !b->query_tracks_visible)) { c->err = "batch: targets required"; return SPA3D_ERR_ARG; }
+  if (c->cfg.decoder_num_channels - 128 <= 0) { c->err = "decoder_num_channels must exceed 128"; return SPA3D_ERR_ARG; }
+  return SPA3D_OK;
+}
+
+static int run(spa3d_ctx* c, RunArgs a, void* ws, int64_t ws_bytes, void* stream) {
+  c->err.clear(); c->hip_err = 0;
+  int rc = check_batch(c, a.b, a.mode);
+  if (rc) return rc;
+  c->stream = (hipStream_t)stream;
+  int lo = 1, hi = a.b->B;
+  if (a.chunk > 0) { lo = hi = std::min(a.chunk, a.b->B); }
+  if (dry_need(c, a, lo) > ws_bytes) {
+    c->err = "workspace too small: need " + std::to_string(dry_need(c, a, lo)) + " bytes for chunk " + std::to_string(lo);
+    return SPA3D_ERR_WORKSPACE;
+  }
+  while (lo < hi) {  // largest chunk that fits
+    int mid = (lo + hi + 1) / 2;
+    if (dry_need(c, a, mid) <= ws_bytes) lo = mid; else hi = mid - 1;
+  }
+  c->ar = Arena(); c->ar.base = (char*)ws; c->ar.cap = ws_bytes; c->dry = false;
+  run_dispatch(c, a, lo);
+  if (c->ar.overflow) { c->err = "internal: arena overflow"; return SPA3D_ERR_WORKSPACE; }
+  if (c->hip_err) return SPA3D_ERR_HIP;
+  return SPA3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* spa3d_version(void) { return "spa3d-hip 0.1 (gfx950)"; }
+
+int spa3d_create(const spa3d_config* cfg, spa3d_handle* out) {
+  if (!cfg || !out) return SPA3D_ERR_ARG;
+  if (cfg->num_heads <= 0 || cfg->qkv_size % cfg->num_heads) return SPA3D_ERR_ARG;  // attention.py:147-150
+  if (cfg->qkv_size / cfg->num_heads > 128 || cfg->num_frequencies > 64 || cfg->num_frequencies <= 0) return SPA3D_ERR_ARG;
+  if (cfg->precision != SPA3D_F32 && cfg->precision != SPA3D_BF16) return SPA3D_ERR_ARG;
+  if (cfg->track_token_dim > 2048 || cfg->decoder_num_channels > 2048 || cfg->encoder_latent_dim > 2048) return SPA3D_ERR_ARG;
+  spa3d_ctx* c = new (std::nothrow) spa3d_ctx();
+  if (!c) return SPA3D_ERR_ARG;
+  c->cfg = *cfg;
+  build_leaves(c);
+  const char* e = getenv("SPA3D_GEMM_IMPL"); if (e) c->gemm_impl = atoi(e);
+  e = getenv("SPA3D_ATTN_IMPL"); if (e) c->attn_impl = atoi(e);
+  *out = c;
+  return SPA3D_OK;
+}
+int spa3d_destroy(spa3d_handle h) { delete h; return SPA3D_OK; }
+const char* spa3d_last_error(spa3d_handle h) { return h ? h->err.c_str() : "null handle"; }
+int64_t spa3d_param_elems(spa3d_handle h) { return h ? h->nparams : 0; }
+int32_t spa3d_num_leaves(spa3d_handle h) { return h ? (int32_t)h->leaves.size() : 0; }
+int spa3d_leaf_info(spa3d_handle h, int32_t i, char* name, int32_t* ndim, int64_t* shape, int64_t* offset) {
+  if (!h || i < 0 || i >= (int32_t)h->leaves.size()) return SPA3D_ERR_ARG;
+  const Leaf& l = h->leaves[i];
+  if (name) { strncpy(name, l.name.c_str(), 159); name[159] = 0; }
+  if (ndim) *ndim = l.ndim;
+  if (shape) for (int k = 0; k < l.ndim; ++k) shape[k] = l.shape[k];
+  if (offset) *offset = l.offset;
+  return SPA3D_OK;
+}
+
+int64_t spa3d_workspace_bytes(spa3d_handle h, int32_t B, int32_t N, int32_t Q, int32_t T, int32_t chunk, int32_t train) {
+  if (!h || B <= 0 || N <= 0 || Q <= 0 || T <= 0) return -1;
+  spa3d_batch b{}; b.B = B; b.N = N; b.Q = Q; b.T = T; b.discretize = 1;
+  b.dino_features = h->cfg.dino_feature_dim > 0 ? (const void*)0x100000 : nullptr;
+  b.depth_features = h->cfg.depth_feature_dim > 0 ? (const void*)0x100000 : nullptr;
+  RunArgs a{}; a.mode = train ? MODE_TRAIN : MODE_FORWARD; a.b = &b; a.G = train ? (float*)0x100000 : nullptr;
+  return dry_need(h, a, std::max(1, std::min(chunk, B)));
+}
+
+int spa3d_encode(spa3d_handle h, const float* params, const spa3d_batch* b, float* latents, void* ws, int64_t ws_bytes, void* stream) {
+  if (!h || !params || !latents) return SPA3D_ERR_ARG;
+  RunArgs a{}; a.mode = MODE_ENCODE; a.P = params; a.b = b; a.latents_out = latents;
+  return run(h, a, ws, ws_bytes, stream);
+}
+int spa3d_decode(spa3d_handle h, const float* params, const spa3d_batch* b, const float* latents, spa3d_outputs* out, void* ws,
+                 int64_t ws_bytes, void* stream) {
+  if (!h || !params || !latents || !out) return SPA3D_ERR_ARG;
+  RunArgs a{}; a.mode = MODE_DECODE; a.P = params; a.b = b; a.latents_in = latents; a.out = out;
+  return run(h, a, ws, ws_bytes, stream);
+}
+int spa3d_forward(spa3d_handle h, const float* params, const spa3d_batch* b, spa3d_outputs* out, void* ws, int64_t ws_bytes, void* stream) {
+  if (!h || !params || !out) return SPA3D_ERR_ARG;
+  RunArgs a{}; a.mode = MODE_FORWARD; a.P = params; a.b = b; a.out = out;
+  return run(h, a, ws, ws_bytes, stream);
+}
+int spa3d_loss_and_grads(spa3d_handle h, const float* params, const spa3d_batch* b, float denom, float* grads, int32_t accumulate,
+                         float* loss3, spa3d_outputs* out, void* ws, int64_t ws_bytes, void* stream) {
+  if (!h || !params || !grads) return SPA3D_ERR_ARG;
+  RunArgs a{}; a.mode = MODE_TRAIN; a.P = params; a.b = b; a.denom = denom; a.G = grads; a.accumulate = accumulate; a.loss3 = loss3; a.out = out;
+  const char* e = getenv("SPA3D_CHUNK"); if (e) a.chunk = atoi(e);
+  return run(h, a, ws, ws_bytes, stream);
+}
+
+int spa3d_loss(spa3d_handle h, const spa3d_batch* b, const spa3d_outputs* preds, float denom, float* loss3, void* stream) {
+  if (!h || !b || !preds || !loss3 || !preds->tracks || !preds->visible_logits || !b->query_tracks || !b->query_tracks_visible)
+    return SPA3D_ERR_ARG;
+  h->err.clear(); h->hip_err = 0; h->stream = (hipStream_t)stream; h->dry = false;
+  float* scratch = loss3 + 4;  // loss3 points at 12 floats: [0..2] results, [4..11] scratch
+  const int64_t n = (int64_t)b->B * b->Q * h->cfg.num_output_frames;
+  k_zero(h, scratch, 32);
+  k_vis_count(h, b->query_tracks_visible, n, scratch + 2);
+  k_set_denom(h, scratch, denom, scratch + 4);
+  k_loss_from_preds(h, preds->tracks, preds->visible_logits, n, b->query_tracks, b->query_tracks_visible, scratch);
+  k_loss_finalize(h, scratch, scratch + 4, L1_WEIGHT, BCE_WEIGHT, loss3);
+  return h->hip_err ? SPA3D_ERR_HIP : SPA3D_OK;
+}
+
+int spa3d_adamw_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, int64_t step, float clip, float b1,
+                     float b2, float eps, float wd, float* scratch, void* stream) {
+  if (!params || !grads || !m || !v || !scratch || n <= 0) return SPA3D_ERR_ARG;
+  spa3d_ctx c; c.stream = (hipStream_t)stream;
+  k_adamw(&c, params, grads, m, v, n, lr, step, clip, b1, b2, eps, wd, scratch);
+  return c.hip_err ? SPA3D_ERR_HIP : SPA3D_OK;
+}
+int spa3d_uniform_noise(float* out, int64_t n, uint32_t key0, uint32_t key1, void* stream) {
+  if (!out || n <= 0) return SPA3D_ERR_ARG;
+  spa3d_ctx c; c.stream = (hipStream_t)stream;
+  k_uniform_noise(&c, out, n, key0, key1);
+  return c.hip_err ? SPA3D_ERR_HIP : SPA3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,138 @@
+// ops.hip -- single-op C-ABI entry points (spa3d_op_*): each building block of the hot path callable on
+// its own so tests/ can compare every kernel with the oracle.  Thin wrappers over the same kernels the
+// model orchestration uses.
+#include <cmath>
+
+#include "common.hpp"
+
+namespace {
+struct OpCtx : spa3d_ctx {
+  OpCtx(void* stream_, void* ws, int64_t ws_bytes) {
+    stream = (hipStream_t)stream_; ar.base = (char*)ws; ar.cap = ws_bytes;
+  }
+  template <typename U> U* alloc(int64_t n) { return (U*)ar.alloc(n * (int64_t)sizeof(U)); }
+  int status() { return ar.overflow ? SPA3D_ERR_WORKSPACE : (hip_err ? SPA3D_ERR_HIP : SPA3D_OK); }
+};
+
+template <typename T>
+int op_linear(OpCtx& c, const T* A, const T* B, const float* bias, const T* res, T* C, int64_t M, int N, int K, int act, int impl) {
+  GemmDesc d{};
+  d.A = A; d.B = B; d.C = C; d.M = M; d.N = N; d.K = K; d.sAm = K; d.sAk = 1; d.sBk = N; d.sBn = 1; d.sCm = N;
+  d.bias = bias; d.epi = act ? EPI_GELU : EPI_NONE; d.aux = res;
+  if constexpr (sizeof(T) == 2) {
+    if (impl != 1) {
+      T* Bt = c.alloc<T>((int64_t)K * N);
+      if (c.ar.overflow) return SPA3D_ERR_WORKSPACE;
+      k_transpose<T>(&c, B, K, N, Bt);
+      d.Bt = Bt; d.ldBt = K;
+      if (gemm_nt_bf16(&c, d)) return c.status();
+      if (impl == 2) return SPA3D_ERR_ARG;
+    }
+  } else if (impl == 2) return SPA3D_ERR_ARG;
+  gemm_generic<T>(&c, d);
+  return c.status();
+}
+
+template <typename T>
+int op_linear_bwd(OpCtx& c, const T* A, const T* B, const T* dC, T* dA, float* dB, float* dbias, int64_t M, int N, int K, int impl) {
+  if (dA) {  // dA[M,K] = dC[M,N] . B[K,N]^T
+    GemmDesc d{};
+    d.A = dC; d.B = B; d.C = dA; d.M = M; d.N = K; d.K = N; d.sAm = N; d.sAk = 1; d.sBk = 1; d.sBn = N; d.sCm = K;
+    d.Bt = B; d.ldBt = N;
+    bool done = false;
+    if constexpr (sizeof(T) == 2) { if (impl != 1) done = gemm_nt_bf16(&c, d); }
+    if (!done) { if (impl == 2) return SPA3D_ERR_ARG; gemm_generic<T>(&c, d); }
+  }
+  if (dB) {  // dB[K,N] = A[M,K]^T . dC[M,N]
+    k_zero(&c, dB, (int64_t)K * N * 4);
+    GemmDesc d{};
+    d.A = A; d.B = dC; d.C = dB; d.M = K; d.N = N; d.K = M; d.sAm = 1; d.sAk = K; d.sBk = N; d.sBn = 1; d.sCm = N;
+    d.out_f32 = 1; d.accumulate = 1;
+    bool done = false;
+    if constexpr (sizeof(T) == 2) { if (impl != 1) done = gemm_tn_bf16(&c, d); }
+    if (!done) { if (impl == 2) return SPA3D_ERR_ARG; gemm_generic<T>(&c, d); }
+  }
+  if (dbias) { k_zero(&c, dbias, (int64_t)N * 4); k_colsum<T>(&c, dC, M, N, N, dbias); }
+  return c.status();
+}
+}  // namespace
+
+// attention front ends live in attention.hip
+template <typename T>
+void attention_fwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq,
+                   const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, T* o, int impl);
+template <typename T>
+void attention_bwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq,
+                   const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, const T* d_o, T* dq, T* dk, T* dv,
+                   float* dsq, float* dsk, int impl);
+
+extern "C" {
+
+int spa3d_op_sin_embed(const float* x, int64_t rows, int32_t C, int32_t nf, void* out, int32_t dtype, void* stream) {
+  if (!x || !out || nf <= 0 || nf > 64) return SPA3D_ERR_ARG;
+  OpCtx c(stream, nullptr, 0);
+  if (dtype == SPA3D_F32) k_sin_embed<float>(&c, x, rows, C, nf, 1.0f, (float*)out);
+  else k_sin_embed<bf16_t>(&c, x, rows, C, nf, 1.0f, (bf16_t*)out);
+  return c.status();
+}
+
+int spa3d_op_linear(const void* A, const void* B, const float* bias, const void* residual, void* C, int64_t M, int32_t N, int32_t K,
+                    int32_t act, int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream) {
+  if (!A || !B || !C) return SPA3D_ERR_ARG;
+  OpCtx c(stream, ws, ws_bytes);
+  if (dtype == SPA3D_F32) return op_linear<float>(c, (const float*)A, (const float*)B, bias, (const float*)residual, (float*)C, M, N, K, act, impl);
+  return op_linear<bf16_t>(c, (const bf16_t*)A, (const bf16_t*)B, bias, (const bf16_t*)residual, (bf16_t*)C, M, N, K, act, impl);
+}
+int spa3d_op_linear_bwd(const void* A, const void* B, const void* dC, void* dA, float* dB, float* dbias, int64_t M, int32_t N, int32_t K,
+                        int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream) {
+  if (!A || !B || !dC) return SPA3D_ERR_ARG;
+  OpCtx c(stream, ws, ws_bytes);
+  if (dtype == SPA3D_F32) return op_linear_bwd<float>(c, (const float*)A, (const float*)B, (const float*)dC, (float*)dA, dB, dbias, M, N, K, impl);
+  return op_linear_bwd<bf16_t>(c, (const bf16_t*)A, (const bf16_t*)B, (const bf16_t*)dC, (bf16_t*)dA, dB, dbias, M, N, K, impl);
+}
+
+int spa3d_op_layernorm(const void* x, const float* scale, void* y, float* stats, int64_t rows, int32_t d, int32_t dtype, void* stream) {
+  if (!x || !scale || !y || d <= 0 || d > 2048) return SPA3D_ERR_ARG;
+  OpCtx c(stream, nullptr, 0);
+  if (dtype == SPA3D_F32) k_layernorm<float>(&c, (const float*)x, scale, (float*)y, stats, rows, d);
+  else k_layernorm<bf16_t>(&c, (const bf16_t*)x, scale, (bf16_t*)y, stats, rows, d);
+  return c.status();
+}
+int spa3d_op_layernorm_bwd(const void* x, const float* scale, const float* stats, const void* dy, void* dx, float* dscale, int64_t rows,
+                           int32_t d, int32_t dtype, void* stream) {
+  if (!x || !scale || !stats || !dy || !dx || !dscale || d <= 0 || d > 2048) return SPA3D_ERR_ARG;
+  OpCtx c(stream, nullptr, 0);
+  if (dtype == SPA3D_F32) k_layernorm_bwd<float>(&c, (const float*)x, scale, stats, (const float*)dy, (float*)dx, dscale, rows, d, nullptr);
+  else k_layernorm_bwd<bf16_t>(&c, (const bf16_t*)x, scale, stats, (const bf16_t*)dy, (bf16_t*)dx, dscale, rows, d, nullptr);
+  return c.status();
+}
+
+int spa3d_op_attention(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* scale_q,
+                       const float* scale_k, const float* keymask, int64_t nseq, int32_t Sq, int32_t Sk, int32_t H, int32_t Dh, void* o,
+                       int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream) {
+  if (!q || !k || !v || !o || !scale_q || !scale_k || Dh > 128) return SPA3D_ERR_ARG;
+  OpCtx c(stream, ws, ws_bytes);
+  if (dtype == SPA3D_F32)
+    attention_fwd<float>(&c, (const float*)q, (const float*)k, (const float*)v, ldq, ldk, ldv, scale_q, scale_k, keymask, nseq, Sq, Sk, H, Dh,
+                         (float*)o, impl);
+  else
+    attention_fwd<bf16_t>(&c, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, scale_q, scale_k, keymask, nseq, Sq, Sk, H,
+                          Dh, (bf16_t*)o, impl);
+  return c.status();
+}
+int spa3d_op_attention_bwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* scale_q,
+                           const float* scale_k, const float* keymask, int64_t nseq, int32_t Sq, int32_t Sk, int32_t H, int32_t Dh,
+                           const void* d_o, void* dq, void* dk, void* dv, float* dscale_q, float* dscale_k, int32_t dtype, int32_t impl,
+                           void* ws, int64_t ws_bytes, void* stream) {
+  if (!q || !k || !v || !d_o || !dq || !dk || !dv || !dscale_q || !dscale_k || Dh > 128) return SPA3D_ERR_ARG;
+  OpCtx c(stream, ws, ws_bytes);
+  if (dtype == SPA3D_F32)
+    attention_bwd<float>(&c, (const float*)q, (const float*)k, (const float*)v, ldq, ldk, ldv, scale_q, scale_k, keymask, nseq, Sq, Sk, H, Dh,
+                         (const float*)d_o, (float*)dq, (float*)dk, (float*)dv, dscale_q, dscale_k, impl);
+  else
+    attention_bwd<bf16_t>(&c, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, scale_q, scale_k, keymask, nseq, Sq, Sk, H,
+                          Dh, (const bf16_t*)d_o, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, dscale_q, dscale_k, impl);
+  return c.status();
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+/* spa3d.h -- C-ABI of libspa3d_hip.so: the MI355X (gfx950) implementation of the 3DSPA
+ * TrackAutoEncoder3D train-step hot path.
+ *
+ * The reference (TheProParadox/3dspa_code) has no FFI: its boundary is the Flax module
+ * protocol.  Each entry point below names the reference call it replaces:
+ *
+ *   spa3d_create / spa3d_leaf_*     TrackAutoEncoder3D(...) + model.init(rng, batch)['params']
+ *                                   track_autoencoder_3d.py:43-115, train.py:221-233
+ *   spa3d_encode                    TrackAutoEncoder3D.encode            track_autoencoder_3d.py:190-204
+ *   spa3d_decode                    get_decoder_context + decode         track_autoencoder_3d.py:206-307
+ *   spa3d_forward                   model.apply({'params': p}, batch)    track_autoencoder_3d.py:309-357
+ *   spa3d_loss                      compute_loss_3d                      train.py:96-129
+ *   spa3d_loss_and_grads            jax.value_and_grad(loss_fn)(params)  train.py:134-162
+ *   spa3d_adamw_step                optax.chain(clip_by_global_norm(1.0), adamw(lr, 0.01)) + apply_updates
+ *                                   train.py:164-165,239-242 (intended semantics, repair R6)
+ *   spa3d_uniform_noise             jax.random.uniform(PRNGKey(0), shape) track_autoencoder_3d.py:254-257
+ *   spa3d_op_*                      single building blocks (attention.py, track_autoencoder.py:18-38),
+ *                                   exported so tests can check each kernel against the oracle.
+ *
+ * Rules: plain C; every function returns an int status (0 = ok) and never throws; no
+ * allocation inside (the caller supplies one workspace from its own allocator); every call
+ * is asynchronous on the hipStream_t passed as `void* stream`; one handle per stream
+ * (thread-compatible, not thread-safe).  All tensors are row-major contiguous in the
+ * reference's layouts.  Parameters and gradients are ONE flat float32 buffer each whose
+ * leaf order / offsets the library defines (spa3d_leaf_*); names are the Flax paths of
+ * SURVEY.md 0.3 and shapes are Flax shapes ([in,out] kernels, [in,H,Dh] / [H,Dh,out]).
+ */
+#ifndef SPA3D_H_
+#define SPA3D_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPA3D_OK 0
+#define SPA3D_ERR_ARG 1      /* bad argument / unsupported shape           */
+#define SPA3D_ERR_WORKSPACE 2 /* workspace too small for even one sample    */
+#define SPA3D_ERR_HIP 3      /* a HIP runtime call or launch failed        */
+
+#define SPA3D_F32 0  /* exact-fp32 path: v_mfma_f32_16x16x4_f32, fp32 activations (parity runs) */
+#define SPA3D_BF16 1 /* bf16 activations + bf16 MFMA, fp32 accumulate, fp32 master params/grads  */
+
+typedef struct spa3d_ctx* spa3d_handle;
+
+/* Hyper-parameters: fields of TrackAutoEncoder3D (track_autoencoder_3d.py:53-67) plus the
+ * transformer sizes hard-coded in setup() (:89-112) and the compute precision. */
+typedef struct {
+  int32_t num_output_frames;   /* 150 */
+  int32_t num_latent_tokens;   /* 128 */
+  int32_t latent_token_dim;    /* 96  */
+  int32_t num_frequencies;     /* 32  */
+  float track_scale_factor;    /* 1.0 */
+  float time_scale_factor;     /* 150.0 */
+  int32_t track_token_dim;     /* 384 */
+  int32_t encoder_latent_dim;  /* 512 */
+  int32_t decoder_num_channels;/* 1280 */
+  int32_t dino_feature_dim;    /* 768; 0 = no dino_projection leaf (use_dino False / key absent) */
+  int32_t depth_feature_dim;   /* channels of depth_features actually fed; 0 = no depth_projection */
+  int32_t num_heads;           /* 8 */
+  int32_t qkv_size;            /* 768 */
+  int32_t enc_mlp, enc_layers; /* 1536, 3 */
+  int32_t t2l_mlp, t2l_layers; /* 2048, 4 */
+  int32_t dec_mlp, dec_layers; /* 2048, 4 */
+  int32_t ro_mlp, ro_layers;   /* 1536, 4 */
+  int32_t precision;           /* SPA3D_F32 | SPA3D_BF16 */
+} spa3d_config;
+
+/* One batch: TrackAutoEncoder3DInputs (track_autoencoder_3d.py:23-40) + the loss targets
+ * read from the same dict (train.py:99-100).  Device pointers. */
+typedef struct {
+  int32_t B, N, Q, T;
+  const float* support_tracks;          /* [B,N,T,3] f32 */
+  const float* support_tracks_visible;  /* [B,N,T,1] f32, 0/1 */
+  const float* query_points;            /* [B,Q,4] f32 (t,x,y,z); required (host builds the default grid) */
+  const int32_t* boundary_frame;        /* [B] */
+  const void* dino_features;            /* [B,N,T,dino_feature_dim] or NULL; f32 in F32 mode, bf16 in BF16 mode */
+  const void* depth_features;           /* [B,N,T,depth_feature_dim] or NULL; same dtype rule */
+  const float* noise;                   /* [B,L,latent_token_dim] uniform [0,1) or NULL */
+  int32_t discretize;                   /* decode(discretize=...); with noise==NULL the library draws
+                                           spa3d_uniform_noise (legacy threefry layout) itself */
+  const float* query_tracks;            /* [B,Q,T,3] f32 targets (loss entry points only) */
+  const float* query_tracks_visible;    /* [B,Q,T,1] f32 targets */
+} spa3d_batch;
+
+/* TrackAutoEncoderResults (track_autoencoder.py:72-91); certain_logits is identically 0. */
+typedef struct {
+  float* tracks;          /* [B,Q,T_out,3] f32 */
+  float* visible_logits;  /* [B,Q,T_out,1] f32 */
+  float* certain_logits;  /* [B,Q,T_out,1] f32 or NULL */
+  float* latents;         /* [B,L,latent_token_dim] f32 or NULL: encode() output */
+} spa3d_outputs;
+
+const char* spa3d_version(void);
+int spa3d_create(const spa3d_config* cfg, spa3d_handle* out);
+int spa3d_destroy(spa3d_handle h);
+const char* spa3d_last_error(spa3d_handle h);
+
+/* parameter tree */
+int64_t spa3d_param_elems(spa3d_handle h);
+int32_t spa3d_num_leaves(spa3d_handle h);
+/* name: >=160 bytes; shape: >=4 int64; offset in floats into the flat buffer */
+int spa3d_leaf_info(spa3d_handle h, int32_t i, char* name, int32_t* ndim, int64_t* shape, int64_t* offset);
+
+/* Bytes of workspace needed to process `chunk` samples at a time (1 <= chunk <= B) of a
+ * [B,N,Q,T] batch; train!=0 sizes forward+backward, else forward only. */
+int64_t spa3d_workspace_bytes(spa3d_handle h, int32_t B, int32_t N, int32_t Q, int32_t T, int32_t chunk, int32_t train);
+
+int spa3d_encode(spa3d_handle h, const float* params, const spa3d_batch* b, float* latents,
+                 void* ws, int64_t ws_bytes, void* stream);
+int spa3d_decode(spa3d_handle h, const float* params, const spa3d_batch* b, const float* latents,
+                 spa3d_outputs* out, void* ws, int64_t ws_bytes, void* stream);
+int spa3d_forward(spa3d_handle h, const float* params, const spa3d_batch* b, spa3d_outputs* out,
+                  void* ws, int64_t ws_bytes, void* stream);
+
+/* loss3 (device, >= 12 floats: [0..2] = total, position, visible; the rest is scratch).
+ * denom<=0: use max(sum(visible),1) of this batch. */
+int spa3d_loss(spa3d_handle h, const spa3d_batch* b, const spa3d_outputs* preds, float denom,
+               float* loss3, void* stream);
+
+/* forward + loss + backward.  grads (flat f32, same layout as params) is OVERWRITTEN unless
+ * accumulate!=0.  denom: global sum(query_tracks_visible) for data-parallel runs (the loss
+ * normalisers are batch-global, train.py:111-113,119-121); <=0 = this batch's own.
+ * loss3 (device): {total, position, visible} with that denominator.  out may be NULL. */
+int spa3d_loss_and_grads(spa3d_handle h, const float* params, const spa3d_batch* b, float denom,
+                         float* grads, int32_t accumulate, float* loss3, spa3d_outputs* out,
+                         void* ws, int64_t ws_bytes, void* stream);
+
+/* clip_by_global_norm(clip) -> adamw(b1,b2,eps,wd) -> apply_updates on flat buffers, in place.
+ * step = optimizer count BEFORE this update (bias correction uses step+1).
+ * scratch: >= 4 KiB device; scratch[0] returns the global grad norm. */
+int spa3d_adamw_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr,
+                     int64_t step, float clip, float b1, float b2, float eps, float wd,
+                     float* scratch, void* stream);
+
+/* jax.random.uniform(PRNGKey(0),[n]) in the legacy (non-partitionable) threefry layout. */
+int spa3d_uniform_noise(float* out, int64_t n, uint32_t key0, uint32_t key1, void* stream);
+
+/* ---- single-op entry points (tests / benchmarks).  dtype: SPA3D_F32 | SPA3D_BF16 for the
+ * activation tensors (void*); parameters, statistics and gradients of parameters are f32. ---- */
+
+/* out[rows, C*2*nf] = SinusoidalEmbedding(x[rows,C]) (track_autoencoder.py:18-38) */
+int spa3d_op_sin_embed(const float* x, int64_t rows, int32_t C, int32_t nf, void* out, int32_t dtype, void* stream);
+
+/* C[M,N] = act(A[M,K] @ B[K,N] + bias) (+ residual); A,B,C,residual dense row-major `dtype`;
+ * act: 0 none, 1 tanh-gelu.  impl: 0 auto, 1 generic kernel, 2 tiled bf16 kernel (error if unusable). */
+int spa3d_op_linear(const void* A, const void* B, const float* bias, const void* residual, void* C,
+                    int64_t M, int32_t N, int32_t K, int32_t act, int32_t dtype, int32_t impl,
+                    void* ws, int64_t ws_bytes, void* stream);
+/* dA[M,K] = dC @ B^T ; dB[K,N] (f32, overwritten) = A^T @ dC ; dbias[N] (f32, overwritten) = colsum(dC) */
+int spa3d_op_linear_bwd(const void* A, const void* B, const void* dC, void* dA, float* dB, float* dbias,
+                        int64_t M, int32_t N, int32_t K, int32_t dtype, int32_t impl,
+                        void* ws, int64_t ws_bytes, void* stream);
+
+/* y = LayerNorm(x)*scale (no bias, eps 1e-6, fast variance); stats[rows,2] = (mean, rstd) */
+int spa3d_op_layernorm(const void* x, const float* scale, void* y, float* stats, int64_t rows, int32_t d,
+                       int32_t dtype, void* stream);
+int spa3d_op_layernorm_bwd(const void* x, const float* scale, const float* stats, const void* dy, void* dx,
+                           float* dscale /* f32[d], accumulated into */, int64_t rows, int32_t d, int32_t dtype, void* stream);
+
+/* Multi-head attention core of ImprovedMHDPAttention (attention.py:166-175): per-head RMSNorm of
+ * q and k (scales f32[Dh]), q/sqrt(Dh), key mask (f32 [nseq,Sk] or NULL, non-zero = keep),
+ * softmax, PV.  q [nseq,Sq,H*Dh] with row stride ldq (elements); k,v [nseq,Sk,H*Dh] strides ldk/ldv;
+ * o [nseq,Sq,H*Dh] dense.  impl: 0 auto, 1 generic (GEMM+softmax kernels), 2 fused kernel. */
+int spa3d_op_attention(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv,
+                       const float* scale_q, const float* scale_k, const float* keymask,
+                       int64_t nseq, int32_t Sq, int32_t Sk, int32_t H, int32_t Dh, void* o,
+                       int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream);
+/* gradients of the above: dq,dk,dv dense-strided like q,k,v (same ld*); dscale_q/k f32[Dh] accumulated into */
+int spa3d_op_attention_bwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv,
+                           const float* scale_q, const float* scale_k, const float* keymask,
+                           int64_t nseq, int32_t Sq, int32_t Sk, int32_t H, int32_t Dh,
+                           const void* d_o, void* dq, void* dk, void* dv, float* dscale_q, float* dscale_k,
+                           int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPA3D_H_ */

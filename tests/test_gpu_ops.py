@@ -1,0 +1,237 @@
+"""GPU parity of every single-op C-ABI entry point (spa3d_op_*) against the CPU oracle.
+fp32 ops use the exact-f32 MFMA path: tolerance 1e-4 absolute on O(1) values (north_star) -- in practice ~1e-6.
+bf16 ops: inputs are rounded to bf16 first, the oracle runs in fp64 on those rounded inputs, and the tolerance
+(2e-2 relative Frobenius, written per test) covers bf16 output rounding + bf16 intermediate P / normalised q,k."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from util import O, max_abs, rel_err
+
+pytestmark = pytest.mark.gpu
+
+F32, BF16 = 0, 1
+
+
+@pytest.fixture(scope='module')
+def lib():
+  import spa3d
+  return spa3d._lib.load()
+
+
+def _s():
+  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ws(nbytes=256 << 20):
+  return torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+
+
+def _dt(dtype):
+  return torch.float32 if dtype == F32 else torch.bfloat16
+
+
+# ------------------------------------------------------------------------------------------------
+def test_sin_embed_matches_oracle_and_kat(lib):
+  g = torch.Generator().manual_seed(0)
+  x = torch.rand(1000, 4, generator=g) * 2 - 0.5
+  x[0] = 0.0
+  out = torch.empty(1000, 256, device='cuda')
+  assert lib.spa3d_op_sin_embed(x.cuda().data_ptr(), 1000, 4, 32, out.data_ptr(), F32, _s()) == 0
+  ref = O.sinusoidal_embedding(x)  # fp32 argument arithmetic, fp32 sin
+  # identical argument rounding; the two libm sinf differ by <= 2 ulp of 1.0
+  assert max_abs(out, ref) < 5e-7
+  # KAT: x = 0 -> [0]*32 + [sin(fl32(pi/2))]*32 per coordinate, layout "(coords d)"
+  row = out[0].cpu().view(4, 64)
+  assert torch.all(row[:, :32] == 0) and torch.allclose(row[:, 32:], torch.ones(4, 32), atol=1e-7)
+
+
+@pytest.mark.parametrize('dtype', [F32, BF16])
+@pytest.mark.parametrize('M,N,K,act,res', [(200, 96, 64, 0, False), (130, 600, 1280, 0, True), (77, 50, 33, 1, True),
+                                           (1024, 384, 256, 1, False)])
+def test_linear_generic(lib, dtype, M, N, K, act, res):
+  g = torch.Generator().manual_seed(1)
+  A = torch.randn(M, K, generator=g).to(_dt(dtype))
+  B = (torch.randn(K, N, generator=g) / math.sqrt(K)).to(_dt(dtype))
+  bias = torch.randn(N, generator=g)
+  R = torch.randn(M, N, generator=g).to(_dt(dtype)) if res else None
+  Cd = torch.empty(M, N, device='cuda', dtype=_dt(dtype))
+  ws = _ws()
+  Ad, Bd, bd = A.cuda(), B.cuda(), bias.cuda()
+  Rd = R.cuda() if res else None
+  rc = lib.spa3d_op_linear(Ad.data_ptr(), Bd.data_ptr(), bd.data_ptr(), Rd.data_ptr() if res else None, Cd.data_ptr(), M, N, K, act,
+                           dtype, 1, ws.data_ptr(), ws.numel(), _s())
+  assert rc == 0
+  ref = A.double() @ B.double() + bias.double()
+  if act:
+    ref = O.gelu_tanh(ref)
+  if res:
+    ref = ref + R.double()
+  if dtype == F32:
+    assert max_abs(Cd, ref) < 1e-4
+  else:
+    assert rel_err(Cd.float(), ref) < 1e-2  # one bf16 rounding of the output (2^-9 relative)
+
+
+@pytest.mark.parametrize('dtype', [F32, BF16])
+@pytest.mark.parametrize('M,N,K', [(300, 96, 64), (5000, 130, 70)])
+def test_linear_bwd_generic(lib, dtype, M, N, K):
+  g = torch.Generator().manual_seed(2)
+  A = torch.randn(M, K, generator=g).to(_dt(dtype))
+  B = (torch.randn(K, N, generator=g) / math.sqrt(K)).to(_dt(dtype))
+  dC = torch.randn(M, N, generator=g).to(_dt(dtype))
+  dA = torch.empty(M, K, device='cuda', dtype=_dt(dtype))
+  dB = torch.empty(K, N, device='cuda')
+  db = torch.empty(N, device='cuda')
+  ws = _ws()
+  Ad, Bd, dCd = A.cuda(), B.cuda(), dC.cuda()
+  rc = lib.spa3d_op_linear_bwd(Ad.data_ptr(), Bd.data_ptr(), dCd.data_ptr(), dA.data_ptr(), dB.data_ptr(), db.data_ptr(), M, N, K, dtype,
+                               1, ws.data_ptr(), ws.numel(), _s())
+  assert rc == 0
+  rA = dC.double() @ B.double().T
+  rB = A.double().T @ dC.double()
+  rb = dC.double().sum(0)
+  tol = 1e-5 if dtype == F32 else 1e-2
+  assert rel_err(dA.float(), rA) < tol
+  assert rel_err(dB, rB) < (1e-5 if dtype == F32 else 1e-5)  # fp32 accumulation of exact bf16 products
+  assert rel_err(db, rb) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', [F32, BF16])
+@pytest.mark.parametrize('d', [384, 512, 1152, 1280, 48])
+def test_layernorm_fwd_bwd(lib, dtype, d):
+  rows = 333
+  g = torch.Generator().manual_seed(3)
+  x = (torch.randn(rows, d, generator=g) * 2 + 0.5).to(_dt(dtype))
+  scale = 1 + 0.1 * torch.randn(d, generator=g)
+  dy = torch.randn(rows, d, generator=g).to(_dt(dtype))
+  xd, sd, dyd = x.cuda(), scale.cuda(), dy.cuda()
+  y = torch.empty_like(xd)
+  stats = torch.empty(rows, 2, device='cuda')
+  assert lib.spa3d_op_layernorm(xd.data_ptr(), sd.data_ptr(), y.data_ptr(), stats.data_ptr(), rows, d, dtype, _s()) == 0
+  xr = x.double().requires_grad_(True)
+  sr = scale.double().requires_grad_(True)
+  yr = O.layer_norm(xr, sr)
+  yr.backward(dy.double())
+  dx = torch.empty_like(xd)
+  ds = torch.zeros(d, device='cuda')
+  assert lib.spa3d_op_layernorm_bwd(xd.data_ptr(), sd.data_ptr(), stats.data_ptr(), dyd.data_ptr(), dx.data_ptr(), ds.data_ptr(), rows, d,
+                                    dtype, _s()) == 0
+  if dtype == F32:
+    assert max_abs(y, yr.detach()) < 1e-5
+    assert max_abs(dx, xr.grad) < 1e-5
+    assert rel_err(ds, sr.grad) < 1e-5
+  else:
+    assert rel_err(y.float(), yr.detach()) < 1e-2
+    assert rel_err(dx.float(), xr.grad) < 1e-2
+    assert rel_err(ds, sr.grad) < 1e-2
+
+
+def _attn_ref(q, k, v, sq, sk, km, H, Dh):
+  """oracle attention core on [nseq,S,H*Dh] tensors (attention.py:166-175)."""
+  nseq, Sq, _ = q.shape
+  Sk = k.shape[1]
+  qh = O.rms_norm(q.view(nseq, Sq, H, Dh), sq)
+  kh = O.rms_norm(k.view(nseq, Sk, H, Dh), sk)
+  vh = v.view(nseq, Sk, H, Dh)
+  mask = None if km is None else km[:, None, None, :].expand(nseq, H, Sq, Sk)
+  return O.dot_product_attention(qh, kh, vh, mask).reshape(nseq, Sq, H * Dh)
+
+
+@pytest.mark.parametrize('dtype', [F32, BF16])
+@pytest.mark.parametrize('nseq,Sq,Sk,H,Dh,masked,packed', [(5, 25, 25, 8, 96, True, True), (3, 129, 129, 8, 96, False, True),
+                                                          (2, 128, 200, 8, 96, False, False), (4, 9, 9, 2, 16, True, True),
+                                                          (2, 151, 151, 8, 96, True, True)])
+def test_attention_fwd_bwd_generic(lib, dtype, nseq, Sq, Sk, H, Dh, masked, packed):
+  E = H * Dh
+  g = torch.Generator().manual_seed(4)
+  dt = _dt(dtype)
+  if packed:  # q|k|v interleaved per token like the fused QKV projection output
+    qkv = torch.randn(nseq, Sq, 3 * E, generator=g).to(dt)
+    q, k, v = qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]
+    ldq = ldk = ldv = 3 * E
+    qkvd = qkv.cuda()
+    qd, kd, vd = qkvd[..., :E], qkvd[..., E:2 * E], qkvd[..., 2 * E:]
+  else:
+    q = torch.randn(nseq, Sq, E, generator=g).to(dt)
+    kv = torch.randn(nseq, Sk, 2 * E, generator=g).to(dt)
+    k, v = kv[..., :E], kv[..., E:]
+    ldq, ldk, ldv = E, 2 * E, 2 * E
+    qd = q.cuda()
+    kvd = kv.cuda()
+    kd, vd = kvd[..., :E], kvd[..., E:]
+  sq = 1 + 0.2 * torch.randn(Dh, generator=g)
+  sk = 1 + 0.2 * torch.randn(Dh, generator=g)
+  km = None
+  if masked:
+    km = (torch.rand(nseq, Sk, generator=g) < 0.8).float()
+    km[:, 0] = 1.0
+    km[0, 1:] = 0.0  # a sequence where only the readout key is visible
+  d_o = torch.randn(nseq, Sq, E, generator=g).to(dt)
+  sqd, skd = sq.cuda(), sk.cuda()
+  kmd = km.cuda() if masked else None
+  o = torch.empty(nseq, Sq, E, device='cuda', dtype=dt)
+  ws = _ws(512 << 20)
+  rc = lib.spa3d_op_attention(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), ldq, ldk, ldv, sqd.data_ptr(), skd.data_ptr(),
+                              kmd.data_ptr() if masked else None, nseq, Sq, Sk, H, Dh, o.data_ptr(), dtype, 1, ws.data_ptr(), ws.numel(),
+                              _s())
+  assert rc == 0
+  qr = q.double().contiguous().requires_grad_(True)
+  kr = k.double().contiguous().requires_grad_(True)
+  vr = v.double().contiguous().requires_grad_(True)
+  sqr = sq.double().requires_grad_(True)
+  skr = sk.double().requires_grad_(True)
+  ref = _attn_ref(qr, kr, vr, sqr, skr, km, H, Dh)
+  ref.backward(d_o.double())
+  # backward
+  dod = d_o.cuda()
+  if packed:
+    dqkv = torch.zeros(nseq, Sq, 3 * E, device='cuda', dtype=dt)
+    dq, dk, dv = dqkv[..., :E], dqkv[..., E:2 * E], dqkv[..., 2 * E:]
+  else:
+    dq = torch.zeros(nseq, Sq, E, device='cuda', dtype=dt)
+    dkv = torch.zeros(nseq, Sk, 2 * E, device='cuda', dtype=dt)
+    dk, dv = dkv[..., :E], dkv[..., E:]
+  dsq = torch.zeros(Dh, device='cuda')
+  dsk = torch.zeros(Dh, device='cuda')
+  rc = lib.spa3d_op_attention_bwd(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), ldq, ldk, ldv, sqd.data_ptr(), skd.data_ptr(),
+                                  kmd.data_ptr() if masked else None, nseq, Sq, Sk, H, Dh, dod.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                  dv.data_ptr(), dsq.data_ptr(), dsk.data_ptr(), dtype, 1, ws.data_ptr(), ws.numel(), _s())
+  assert rc == 0
+  if dtype == F32:
+    assert max_abs(o, ref.detach()) < 1e-5
+    for got, want in ((dq, qr.grad), (dk, kr.grad), (dv, vr.grad), (dsq, sqr.grad), (dsk, skr.grad)):
+      assert rel_err(got.float(), want) < 1e-4
+  else:
+    assert rel_err(o.float(), ref.detach()) < 2e-2
+    for got, want in ((dq, qr.grad), (dk, kr.grad), (dv, vr.grad), (dsq, sqr.grad), (dsk, skr.grad)):
+      assert rel_err(got.float(), want) < 3e-2
+
+
+def test_uniform_noise_matches_threefry_restatement(lib):
+  from oracle import np_blocks as NB
+  n = 2 * 8 * 16 + 1  # odd length exercises the padding rule
+  out = torch.empty(n, device='cuda')
+  assert lib.spa3d_uniform_noise(out.data_ptr(), n, 0, 0, _s()) == 0
+  ref = NB.jax_uniform_legacy((n,))
+  assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_adamw_step_matches_oracle(lib):
+  g = torch.Generator().manual_seed(5)
+  n = 100003
+  p = torch.randn(n, generator=g)
+  gr = torch.randn(n, generator=g) * 0.01
+  m = torch.randn(n, generator=g) * 0.001
+  v = torch.rand(n, generator=g) * 1e-4
+  pd, gd, md, vd = p.cuda(), gr.cuda(), m.cuda(), v.cuda()
+  scratch = torch.zeros(1024, device='cuda')
+  assert lib.spa3d_adamw_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, 3e-4, 7, 1.0, 0.9, 0.999, 1e-8, 0.01,
+                              scratch.data_ptr(), _s()) == 0
+  P, G, M, V = {'a': p.double().clone()}, {'a': gr.double()}, {'a': m.double().clone()}, {'a': v.double().clone()}
+  gn = O.adamw_step(P, G, M, V, step=7, lr=3e-4)
+  assert abs(float(scratch[0]) - gn) / gn < 1e-5
+  assert max_abs(pd, P['a']) < 1e-6 and max_abs(md, M['a']) < 1e-7 and max_abs(vd, V['a']) < 1e-9

@@ -1,0 +1,52 @@
+"""Shared helpers for the parity tests: tiny configs, oracle<->product parameter exchange."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+from oracle import spa3d_oracle as O  # noqa: E402  (tests may use the oracle; the product never does)
+
+MINI = dict(num_output_frames=8, num_latent_tokens=8, latent_token_dim=16, num_frequencies=4, track_token_dim=32,
+            encoder_latent_dim=48, decoder_num_channels=192, num_heads=2, qkv_size=32, enc_mlp=64, enc_layers=2, t2l_mlp=64,
+            t2l_layers=2, dec_mlp=64, dec_layers=1, ro_mlp=64, ro_layers=2)
+
+
+def oracle_cfg(**kw):
+  return O.Config(**kw)
+
+
+def product_model(spa3d, cfg: O.Config, precision='fp32'):
+  m = spa3d.TrackAutoEncoder3D(
+      num_output_frames=cfg.num_output_frames, num_latent_tokens=cfg.num_latent_tokens, latent_token_dim=cfg.latent_token_dim,
+      num_frequencies=cfg.num_frequencies, track_scale_factor=cfg.track_scale_factor, time_scale_factor=cfg.time_scale_factor,
+      track_token_dim=cfg.track_token_dim, encoder_latent_dim=cfg.encoder_latent_dim,
+      decoder_num_channels=cfg.decoder_num_channels, dino_feature_dim=cfg.dino_feature_dim,
+      depth_feature_dim=cfg.depth_feature_dim, use_dino=cfg.use_dino, use_depth=cfg.use_depth, precision=precision)
+  m.num_heads, m.qkv_size = cfg.num_heads, cfg.qkv_size
+  m.enc_mlp, m.enc_layers = cfg.enc_mlp, cfg.enc_layers
+  m.t2l_mlp, m.t2l_layers = cfg.t2l_mlp, cfg.t2l_layers
+  m.dec_mlp, m.dec_layers = cfg.dec_mlp, cfg.dec_layers
+  m.ro_mlp, m.ro_layers = cfg.ro_mlp, cfg.ro_layers
+  return m
+
+
+def tree_to(tree, device=None, dtype=None):
+  return O.tree_map(lambda t: t.to(device=device, dtype=dtype) if dtype or device else t, tree)
+
+
+def batch_to(batch, device):
+  return {k: v.to(device) for k, v in batch.items()}
+
+
+def max_abs(a, b):
+  return float((a.double().cpu() - b.double().cpu()).abs().max())
+
+
+def rel_err(a, b):
+  a, b = a.double().cpu(), b.double().cpu()
+  return float((a - b).norm() / (b.norm() + 1e-30))
