@@ -4,8 +4,8 @@ The directory name is not a Python identifier; import it as `import spa3d` (repo
 `importlib.import_module('3dspa_code_amd')`."""
 from . import _lib
 from .model import (ParamTree, TrackAutoEncoder3D, TrackAutoEncoderDecoderContext, TrackAutoEncoderResults, compute_loss_3d,
-                    sinusoidal_embedding)
+                    profile_summary, sinusoidal_embedding)
 from .train import TrainState, create_learning_rate_schedule
 
 __all__ = ['TrackAutoEncoder3D', 'TrackAutoEncoderResults', 'TrackAutoEncoderDecoderContext', 'ParamTree', 'compute_loss_3d',
-           'sinusoidal_embedding', 'TrainState', 'create_learning_rate_schedule', '_lib']
+           'sinusoidal_embedding', 'profile_summary', 'TrainState', 'create_learning_rate_schedule', '_lib']

@@ -70,6 +70,19 @@ struct Arena {  // bump allocator over the caller's workspace; dry mode only cou
   void release(int64_t m) { off = m; }
 };
 
+// live per-kernel-class timing with HIP events on the launch stream (bench.py "roofline"; off by default)
+enum { PROF_GEMM_NT = 0, PROF_GEMM_TN = 1, PROF_GEMM_GENERIC = 2, PROF_ATTN_FWD = 3, PROF_ATTN_BWD = 4, PROF_NCLS = 5 };
+struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; };
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> pool; size_t used = 0;
+  std::vector<ProfRec> recs;
+  hipEvent_t get() {
+    if (used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
+    return pool[used++];
+  }
+};
+
 struct spa3d_ctx {
   spa3d_config cfg;
   std::vector<Leaf> leaves;
@@ -81,6 +94,18 @@ struct spa3d_ctx {
   int hip_err = 0;
   int gemm_impl = 0;  // 0 auto, 1 generic only
   int attn_impl = 0;
+  Prof prof;
+};
+
+struct ProfScope {  // records an event pair around the launches issued in its lifetime
+  spa3d_ctx* c; ProfRec r; bool on;
+  ProfScope(spa3d_ctx* c_, int cls, double flops, double bytes) : c(c_), on(c_->prof.on && !c_->dry) {
+    if (!on) return;
+    r.cls = cls; r.flops = flops; r.bytes = bytes; r.e0 = c->prof.get(); r.e1 = c->prof.get();
+    if (!r.e0 || !r.e1) { on = false; return; }
+    (void)hipEventRecord(r.e0, c->stream);
+  }
+  ~ProfScope() { if (on) { (void)hipEventRecord(r.e1, c->stream); c->prof.recs.push_back(r); } }
 };
 
 #define SPA_LAUNCH_CHECK(ctx)                                                     \

@@ -177,6 +177,8 @@ void gemm_generic(spa3d_ctx* c, const GemmDesc& d) {
     if (!c->hip_err) { c->hip_err = -1; c->err = "gemm_generic: grid too large"; }
     return;
   }
+  ProfScope ps(c, PROF_GEMM_GENERIC, 2.0 * (double)d.M * d.N * d.K * (double)nbatch,
+               (double)nbatch * ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * sizeof(T));
   gemm_generic_kernel<T><<<(unsigned)blocks, 256, 0, c->stream>>>(g);
   SPA_LAUNCH_CHECK(c);
 }

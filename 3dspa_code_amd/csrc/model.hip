@@ -687,6 +687,25 @@ int spa3d_loss(spa3d_handle h, const spa3d_batch* b, const spa3d_outputs* preds,
   return h->hip_err ? SPA3D_ERR_HIP : SPA3D_OK;
 }
 
+int spa3d_prof_enable(spa3d_handle h, int32_t on) {
+  if (!h) return SPA3D_ERR_ARG;
+  h->prof.on = on != 0; h->prof.used = 0; h->prof.recs.clear();
+  return SPA3D_OK;
+}
+int spa3d_prof_read(spa3d_handle h, int32_t cls, double* out4) {
+  if (!h || !out4 || cls < 0 || cls >= PROF_NCLS) return SPA3D_ERR_ARG;
+  double n = 0, ms = 0, fl = 0, by = 0;
+  for (auto& r : h->prof.recs) {
+    if (r.cls != cls) continue;
+    if (hipEventSynchronize(r.e1) != hipSuccess) return SPA3D_ERR_HIP;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return SPA3D_ERR_HIP;
+    n += 1; ms += t; fl += r.flops; by += r.bytes;
+  }
+  out4[0] = n; out4[1] = ms; out4[2] = fl; out4[3] = by;
+  return SPA3D_OK;
+}
+
 int spa3d_adamw_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr, int64_t step, float clip, float b1,
                      float b2, float eps, float wd, float* scratch, void* stream) {
   if (!params || !grads || !m || !v || !scratch || n <= 0) return SPA3D_ERR_ARG;

@@ -79,7 +79,6 @@ class TrainState:
     denom = self._global_denominator(batch) if self.world > 1 else 0.0
     ld, _, _ = self.model.loss_and_grads(self.params, batch, grads_flat=self.grads, accumulate=False, denom=denom,
                                          discretize=discretize, noise=noise)
-    loss3 = ld['total_loss'].untyped_storage()  # noqa: F841 (keeps the 4-float buffer alive)
     l3 = torch.stack([ld['total_loss'], ld['position_loss'], ld['visible_loss']])
     self._allreduce_grads(l3)
     lr = self.schedule(self.step)

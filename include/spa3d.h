@@ -134,6 +134,12 @@ int spa3d_adamw_step(float* params, const float* grads, float* m, float* v, int6
                      int64_t step, float clip, float b1, float b2, float eps, float wd,
                      float* scratch, void* stream);
 
+/* Live timing of the hot kernel classes with HIP event pairs recorded on the launch stream (bench.py's
+ * "roofline" object).  cls: 0 tiled NT GEMM, 1 tiled TN GEMM (dW), 2 generic GEMM, 3 fused attention fwd,
+ * 4 fused attention bwd.  out4 = {launches, total ms, algorithmic FLOPs, algorithmic bytes}. */
+int spa3d_prof_enable(spa3d_handle h, int32_t on);
+int spa3d_prof_read(spa3d_handle h, int32_t cls, double* out4);
+
 /* jax.random.uniform(PRNGKey(0),[n]) in the legacy (non-partitionable) threefry layout. */
 int spa3d_uniform_noise(float* out, int64_t n, uint32_t key0, uint32_t key1, void* stream);
 
