@@ -138,6 +138,9 @@ struct GemmDesc {
   int atomic = 0;                    // C += via atomicAdd (f32 C only)
   const void* Bt = nullptr;          // optional copy of B stored [N][K] (K contiguous, row stride ldBt) for the tiled kernels
   int64_t ldBt = 0;
+  int32_t crow_group = 0, crow_skip = 0;  // C row m is stored at row m + (m/crow_group + 1)*crow_skip (token rows behind a readout row)
+  int32_t brow_group = 0, brow_skip = 0;  // same remap on B's k index (dW over token rows that skip the readout row)
+  const void* zero_page = nullptr;        // >= 16 B of zeros (tiled TN kernel: rows past the end of the reduction)
 };
 
 template <typename T> void gemm_generic(spa3d_ctx* c, const GemmDesc& d);
@@ -158,7 +161,8 @@ template <typename T> void k_softmax(spa3d_ctx*, T* s, const float* keymask, int
 template <typename T> void k_softmax_bwd(spa3d_ctx*, const T* p, T* dp, int64_t rows, int Sk);
 template <typename T> void k_sin_embed(spa3d_ctx*, const float* x, int64_t rows, int C, int nf, float prescale, T* out);
 template <typename T> void k_embed_tokens(spa3d_ctx*, const float* tracks, int64_t nrows, int T_, int nf, float prescale, T* sinbuf);
-template <typename T> void k_colsum(spa3d_ctx*, const T* x, int64_t rows, int n, int64_t ld, float* out /*accumulated*/);
+template <typename T> void k_colsum(spa3d_ctx*, const T* x, int64_t rows, int n, int64_t ld, float* out /*accumulated*/, int rgroup = 0,
+                                    int rskip = 0);
 template <typename T> void k_gelu(spa3d_ctx*, const T* x, T* y, int64_t n);
 template <typename T> void k_add(spa3d_ctx*, T* dst, const T* src, int64_t n);
 void k_fill(spa3d_ctx*, float* p, float v, int64_t n);

@@ -1,4 +1,331 @@
-// gemm_fast.hip -- LDS-tiled bf16 MFMA GEMMs for the hot shapes (placeholder: not yet enabled).
+// gemm_fast.hip -- LDS-tiled bf16 MFMA GEMMs for the hot shapes of the 3DSPA train step (gfx950).
+//
+// gemm_nt_bf16 :  C[M,N] (op)= epi(A[M,K] . Bt[N,K]^T + bias)            (Y = X.W and dX = dY.W^T; 2/3 of all FLOPs)
+//   128x128x64 tile, 256 threads = 4 waves (2x2), 64x64 per wave as 4x4 v_mfma_f32_16x16x32_bf16,
+//   operands staged HBM->LDS with global_load_lds_dwordx4 (no VGPR round trip), two LDS buffers, the next
+//   K-tile in flight under the current tile's MFMAs.  LDS rows are 128 B; the 16-B chunk index is XORed with
+//   (row & 7) -- on the SOURCE address, because LDS-DMA writes lane-linear (cdna_hip_programming.md rule 21) --
+//   which makes every ds_read_b128 fragment read conflict-free.  MFMA operands are swapped (D = Bt.A^T) so a lane
+//   ends up with 4 consecutive columns of one output row: 8-B bf16 / 16-B f32 stores, vector bias/residual loads.
+//   Workgroup ids are remapped so all N-tiles of one 128-row A panel run on one XCD (its L2 then serves the panel).
+//
+// gemm_tn_bf16 :  C[Ki,N] += A[M,Ki]^T . B[M,N]   (dW = X^T.dY; 1/3 of all FLOPs; reduction over the huge M)
+//   128x128 output tile, 64 reduction rows per LDS tile, v_mfma_f32_32x32x16_bf16; both operands are read from
+//   row-major [m][*] LDS images with ds_read_b64_tr_b16 (hardware transpose), images XOR-swizzled per
+//   cdna_hip_programming.md T10 layout (b).  M is split across workgroups; partial tiles are added with
+//   global_atomic_add_f32 -- one accumulator register of a 32x32 tile is two 128-B row segments per
+//   wave-instruction, the full-rate atomic shape (MI355X_MICROARCH.md "Global float atomics").
 #include "common.hpp"
-bool gemm_nt_bf16(spa3d_ctx*, const GemmDesc&) { return false; }
-bool gemm_tn_bf16(spa3d_ctx*, const GemmDesc&) { return false; }
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+
+#define GLDS16(gptr, lptr) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+struct NtArgs {
+  const bf16_t* A; const bf16_t* Bt; void* C;
+  int64_t M; int N; int K; int64_t lda, ldb, ldc;
+  const float* bias; const bf16_t* aux; int epi; int out_f32; int accumulate; float alpha;
+  int tiles_m, tiles_n, crow_group, crow_skip;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 16 KiB | B 16 KiB]
+  // XCD-aware id: blocks b, b+8, b+16.. share an XCD; give each XCD whole A panels (all N-tiles of an M-tile)
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int tm = (idx / g.tiles_n) * 8 + xcd, tn = idx % g.tiles_n;
+  if (tm >= g.tiles_m) return;
+  const int64_t m0 = (int64_t)tm * 128;
+  const int n0 = tn * 128;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // ---- staging addresses: wave w fills 8-row groups 4w..4w+3 of each operand tile; lane -> (row r = lane>>3, chunk cp = lane&7)
+  const int sr = lane >> 3, scp = lane & 7;
+  const int sc = (scp ^ sr) * 8;  // source chunk (elements) that lands in physical chunk scp of a row with (row&7)==sr
+  const bf16_t* ga[4]; const bf16_t* gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row = (w * 4 + i) * 8 + sr;
+    int64_t am = m0 + row; if (am > g.M - 1) am = g.M - 1;
+    int bn = n0 + row; if (bn > g.N - 1) bn = g.N - 1;
+    ga[i] = g.A + am * g.lda + sc;
+    gb[i] = g.Bt + (int64_t)bn * g.ldb + sc;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* sa = smem + buf * 32768 + (w * 4) * 1024;
+    char* sb = sa + 16384;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) GLDS16(ga[i] + kt * 64, sa + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) GLDS16(gb[i] + kt * 64, sb + i * 1024);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = g.K / 64;
+  stage(0, 0);
+  __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes tile 0
+  // fragment byte offsets inside a tile: row*128 + ((ks*4 + fq) ^ (row&7))*16, row&7 == fr&7
+  const int a_off = (wm + fr) * 128, b_off = (wn + fr) * 128;
+  const int x0 = ((fq) ^ (fr & 7)) * 16, x1 = ((4 + fq) ^ (fr & 7)) * 16;
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) stage(cur ^ 1, t + 1);  // next tile in flight under this tile's MFMAs
+    const char* sa = smem + cur * 32768;
+    const char* sb = sa + 16384;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int xo = ks ? x1 : x0;
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + a_off + i * 2048 + xo);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + b_off + j * 2048 + xo);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading `cur`
+  }
+
+  // ---- epilogue: lane holds C[m = wm+16i+fr][n = wn+16j+4fq .. +3]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t gm = m0 + wm + i * 16 + fr;
+    if (gm >= g.M) continue;
+    int64_t crow = gm;
+    if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gn = n0 + wn + j * 16 + fq * 4;
+      if (gn >= g.N) continue;  // N % 4 == 0 is required, so a 4-group is in or out as a whole
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = g.alpha * acc[i][j][r];
+      if (g.bias) { const float4 b4 = *(const float4*)(g.bias + gn); v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
+      if (g.epi == EPI_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+      }
+      const int64_t ci = crow * g.ldc + gn;
+      if (g.aux) {
+        const u16x4 x4 = *(const u16x4*)(g.aux + ci);
+        if (g.epi == EPI_MUL_GELU_GRAD) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += bf2f(x4[r]);
+        }
+      }
+      if (g.out_f32) {
+        float4* cp = (float4*)((float*)g.C + ci);
+        if (g.accumulate) { const float4 o = *cp; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+        *cp = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        u16x4* cp = (u16x4*)((bf16_t*)g.C + ci);
+        if (g.accumulate) { const u16x4 o = *cp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += bf2f(o[r]); }
+        u16x4 o4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[r] = f2bf(v[r]);
+        *cp = o4;
+      }
+    }
+  }
+}
+
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
+  // needs B as [N][K] with K contiguous: either the explicit transposed copy or B itself when sBk == 1
+  const bf16_t* Bt = nullptr; int64_t ldb = 0;
+  if (d.Bt) { Bt = (const bf16_t*)d.Bt; ldb = d.ldBt; }
+  else if (d.sBk == 1) { Bt = (const bf16_t*)d.B; ldb = d.sBn; }
+  else return false;
+  if (d.sAk != 1 || d.nb1 != 1 || d.nb2 != 1 || d.atomic) return false;
+  if (d.K % 64 || d.N % 4 || d.M < 1 || d.K < 64) return false;
+  if (d.sAm % 8 || ldb % 8 || d.sCm % 4 || !aligned16(d.A) || !aligned16(Bt) || !aligned16(d.C)) return false;
+  if (d.aux && (!aligned16(d.aux) || d.out_f32)) return false;
+  if (d.bias && !aligned16(d.bias)) return false;
+  if ((int64_t)d.M * d.N < 128 * 128) return false;  // tiny problems: the generic kernel has less tail waste
+  if (c->dry) return true;
+  NtArgs g;
+  g.A = (const bf16_t*)d.A; g.Bt = Bt; g.C = d.C; g.M = d.M; g.N = d.N; g.K = d.K; g.lda = d.sAm; g.ldb = ldb; g.ldc = d.sCm;
+  g.bias = d.bias; g.aux = (const bf16_t*)d.aux; g.epi = d.epi; g.out_f32 = d.out_f32; g.accumulate = d.accumulate; g.alpha = d.alpha;
+  g.tiles_m = (int)((d.M + 127) / 128); g.tiles_n = (d.N + 127) / 128;
+  g.crow_group = d.crow_group; g.crow_skip = d.crow_skip;
+  const int64_t blocks = (int64_t)((g.tiles_m + 7) / 8) * 8 * g.tiles_n;
+  if (blocks > 0x7fffffffLL) return false;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
+  ProfScope ps(c, PROF_GEMM_NT, 2.0 * (double)d.M * d.N * d.K, ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * 2.0);
+  gemm_nt_kernel<<<(unsigned)blocks, 256, 65536, c->stream>>>(g);
+  SPA_LAUNCH_CHECK(c);
+  return true;
+}
+
+// =================================================================================================================
+// TN: C[Ki][N] += sum_m A[m][Ki] * B[m][N]
+// =================================================================================================================
+struct TnArgs {
+  const bf16_t* A; const bf16_t* B; float* C; const bf16_t* zero;
+  int64_t M; int Ki; int N; int64_t lda, ldb, ldc;
+  int tiles_i, tiles_n, splits; int64_t rows_per_split;
+  int brow_group, brow_skip;
+};
+
+__device__ __forceinline__ uint2 ds_read_tr16_b64(const void* p) {
+  uint2 v;
+  const unsigned a = (unsigned)(uintptr_t)p;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a) : "memory");
+  return v;
+}
+// byte offset of 16-B chunk `ch` of row `row` in a [rows][128 x bf16] image (T10 layout (b))
+__device__ __forceinline__ int tr_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 64 rows x 256 B | B 64 rows x 256 B]
+  int bid = blockIdx.x;
+  const int tn = bid % g.tiles_n; bid /= g.tiles_n;
+  const int ti = bid % g.tiles_i; bid /= g.tiles_i;
+  const int sp = bid;
+  const int i0 = ti * 128, n0 = tn * 128;
+  const int64_t mbeg = (int64_t)sp * g.rows_per_split;
+  int64_t mend = mbeg + g.rows_per_split; if (mend > g.M) mend = g.M;
+  const int nt = (int)((mend - mbeg + 63) / 64);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wi = (w >> 1) * 64, wn = (w & 1) * 64;
+
+  // ---- staging: one wave-instruction = 4 rows x 256 B; wave w fills rows 16w..16w+15 (4 instructions) of each operand
+  const int sr = lane >> 4, scp = lane & 15;
+  int acol[4], bcol[4];  // source column (elements) per instruction
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = w * 16 + q * 4 + sr;  // row inside the 64-row tile
+    const int ch = scp ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    int ca = i0 + ch * 8; if (ca > g.Ki - 8) ca = g.Ki - 8;   // Ki % 8 == 0; clamped columns are never stored
+    int cb = n0 + ch * 8; if (cb > g.N - 8) cb = g.N - 8;
+    acol[q] = ca; bcol[q] = cb;
+  }
+  auto stage = [&](int buf, int t) {
+    char* sa = smem + buf * 32768 + w * 4096;
+    char* sb = sa + 16384;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t m = mbeg + (int64_t)t * 64 + w * 16 + q * 4 + sr;
+      const bool ok = m < mend;
+      int64_t mb = ok ? m : mend - 1;
+      if (g.brow_group > 0) mb = mb + (mb / g.brow_group + 1) * (int64_t)g.brow_skip;
+      const bf16_t* pa = ok ? g.A + m * g.lda + acol[q] : g.zero;  // rows past the end contribute exactly 0
+      const bf16_t* pb = g.B + mb * g.ldb + bcol[q];
+      GLDS16(pa, sa + q * 1024);
+      GLDS16(pb, sb + q * 1024);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposed-read addressing for the 32x32x16 operands: 16-lane group gq = lane>>4 covers operand rows
+  // (output index) 16*(gq&1)..+15 and k = 8*(gq>>1)..+7; lane 4q+p of the group supplies row k0+q, chunk c0+(p>>1), +8*(p&1)
+  const int gq = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+  const int kq = 8 * (gq >> 1) + lq;       // row inside a 16-row k-step (first read; second read is +4)
+  const int cbase = 2 * (gq & 1) + (lp >> 1);  // chunk inside the 32-wide sub-tile
+  if (nt > 0) stage(0, 0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) stage(cur ^ 1, t + 1);
+    const char* sa = smem + cur * 32768;
+    const char* sb = sa + 16384;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint2 a_lo[2], a_hi[2], b_lo[2], b_hi[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ch = (wi + i * 32) / 8 + cbase;
+        a_lo[i] = ds_read_tr16_b64(sa + tr_off(ks * 16 + kq, ch) + 8 * (lp & 1));
+        a_hi[i] = ds_read_tr16_b64(sa + tr_off(ks * 16 + kq + 4, ch) + 8 * (lp & 1));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ch = (wn + j * 32) / 8 + cbase;
+        b_lo[j] = ds_read_tr16_b64(sb + tr_off(ks * 16 + kq, ch) + 8 * (lp & 1));
+        b_hi[j] = ds_read_tr16_b64(sb + tr_off(ks * 16 + kq + 4, ch) + 8 * (lp & 1));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs below the wait (cdna_hip_programming.md rule 18)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint4 au = make_uint4(a_lo[i].x, a_lo[i].y, a_hi[i].x, a_hi[i].y);
+        const bf16x8 af = __builtin_bit_cast(bf16x8, au);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const uint4 bu = make_uint4(b_lo[j].x, b_lo[j].y, b_hi[j].x, b_hi[j].y);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bu), acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (nt == 0) return;
+  // ---- epilogue: 32x32 C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); one register = two 128-B row segments
+  const int col = lane & 31, rb = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gn = n0 + wn + j * 32 + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gi = i0 + wi + i * 32 + (r & 3) + 8 * (r >> 2) + rb;
+        if (gi < g.Ki && gn < g.N) atomicAdd(g.C + (int64_t)gi * g.ldc + gn, acc[i][j][r]);
+      }
+    }
+}
+
+bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d) {
+  // A[m'=i][k'=m] = X[m][i]: sAm == 1, sAk == lda ; B[k'=m][n]: sBn == 1, sBk == ldb ; f32 accumulate
+  if (d.sAm != 1 || d.sBn != 1 || !d.out_f32 || !d.accumulate || d.nb1 != 1 || d.nb2 != 1) return false;
+  if (d.epi != EPI_NONE || d.aux || d.bias || d.alpha != 1.f || !d.zero_page) return false;
+  const int Ki = (int)d.M, N = d.N; const int64_t M = d.K;
+  if (Ki % 8 || N % 8 || Ki < 8 || N < 8 || M < 256) return false;
+  if (d.sAk % 8 || d.sBk % 8 || !aligned16(d.A) || !aligned16(d.B)) return false;
+  if (c->dry) return true;
+  TnArgs g;
+  g.A = (const bf16_t*)d.A; g.B = (const bf16_t*)d.B; g.C = (float*)d.C; g.zero = (const bf16_t*)d.zero_page;
+  g.M = M; g.Ki = Ki; g.N = N; g.lda = d.sAk; g.ldb = d.sBk; g.ldc = d.sCm;
+  g.tiles_i = (Ki + 127) / 128; g.tiles_n = (N + 127) / 128;
+  g.brow_group = d.brow_group; g.brow_skip = d.brow_skip;
+  const int64_t tiles = (int64_t)g.tiles_i * g.tiles_n;
+  // enough workgroups to fill 256 CUs several times over, but >= 4096 reduction rows per split so the
+  // f32 atomic traffic (4 B per output element per split) stays a few % of the tile's MFMA time
+  int64_t splits = std::max<int64_t>(1, std::min<int64_t>((4096 + tiles - 1) / tiles, (M + 4095) / 4096));
+  int64_t rps = ((M + splits - 1) / splits + 63) / 64 * 64;
+  splits = (M + rps - 1) / rps;
+  g.splits = (int)splits; g.rows_per_split = rps;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
+  ProfScope ps(c, PROF_GEMM_TN, 2.0 * (double)M * Ki * N, ((double)M * Ki + (double)M * N) * 2.0 + (double)Ki * N * 4.0 * splits);
+  gemm_tn_kernel<<<(unsigned)(tiles * splits), 256, 65536, c->stream>>>(g);
+  SPA_LAUNCH_CHECK(c);
+  return true;
+}

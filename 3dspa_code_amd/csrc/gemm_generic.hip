@@ -22,6 +22,7 @@ struct GemmArgs {
   int nb2; int64_t bA1, bA2, bB1, bB2, bC1, bC2;
   float alpha; const float* bias; int epi; const void* aux; int aux_is_residual; int out_f32; int accumulate; int atomic;
   int tiles_m, tiles_n, ksplit; int64_t kchunk;
+  int crow_group, crow_skip, brow_group, brow_skip;
 };
 
 template <typename T>
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs g) {
       for (int it = 0; it < 64 / (256 / BK); ++it) {
         int n = nr + it * (256 / BK);
         int gn = n0 + n; int64_t gk = k0 + kk;
-        Bs[n * LDS_LD + kk] = (gn < g.N && gk < kend) ? B[gk + (int64_t)gn * g.sBn] : zero;
+        int64_t pk = gk; if (g.brow_group > 0) pk = gk + (gk / g.brow_group + 1) * (int64_t)g.brow_skip;
+        Bs[n * LDS_LD + kk] = (gn < g.N && gk < kend) ? B[pk + (int64_t)gn * g.sBn] : zero;
       }
     } else {
       const int n = tid & 63, kr = tid >> 6;
@@ -88,7 +90,8 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs g) {
       for (int it = 0; it < BK / 4; ++it) {
         int kk = kr + it * 4;
         int gn = n0 + n; int64_t gk = k0 + kk;
-        Bs[n * LDS_LD + kk] = (gn < g.N && gk < kend) ? B[gk * g.sBk + (int64_t)gn * g.sBn] : zero;
+        int64_t pk = gk; if (g.brow_group > 0) pk = gk + (gk / g.brow_group + 1) * (int64_t)g.brow_skip;
+        Bs[n * LDS_LD + kk] = (gn < g.N && gk < kend) ? B[pk * g.sBk + (int64_t)gn * g.sBn] : zero;
       }
     }
     __syncthreads();
@@ -131,7 +134,8 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs g) {
         if (gm >= g.M || gn >= g.N) continue;
         float v = g.alpha * acc[i][j][r];
         if (g.bias && ks == 0) v += g.bias[gn];
-        const int64_t ci = coff + gm * g.sCm + gn;
+        int64_t crow = gm; if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
+        const int64_t ci = coff + crow * g.sCm + gn;
         if (g.epi == EPI_GELU) v = gelu_tanh_f(v);
         if (g.aux) {
           float x = ld((const T*)g.aux + ci);
@@ -160,6 +164,7 @@ void gemm_generic(spa3d_ctx* c, const GemmDesc& d) {
   g.nb2 = d.nb2; g.bA1 = d.bA1; g.bA2 = d.bA2; g.bB1 = d.bB1; g.bB2 = d.bB2; g.bC1 = d.bC1; g.bC2 = d.bC2;
   g.alpha = d.alpha; g.bias = d.bias; g.epi = d.epi; g.aux = d.aux; g.aux_is_residual = d.aux_is_residual;
   g.out_f32 = d.out_f32; g.accumulate = d.accumulate; g.atomic = 0;
+  g.crow_group = d.crow_group; g.crow_skip = d.crow_skip; g.brow_group = d.brow_group; g.brow_skip = d.brow_skip;
   g.tiles_m = (int)((d.M + 63) / 64); g.tiles_n = (d.N + 63) / 64;
   int64_t nbatch = (int64_t)d.nb1 * d.nb2;
   int64_t blocks = nbatch * g.tiles_m * g.tiles_n;

@@ -328,23 +328,27 @@ void k_query_embed1(spa3d_ctx* c, const float* qp, int64_t nq, int nf, float tra
 // small helpers
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ x, int64_t rows, int n, int64_t ld_, float* __restrict__ out, int64_t rows_per_block) {
+__global__ void colsum_kernel(const T* __restrict__ x, int64_t rows, int n, int64_t ld_, float* __restrict__ out, int64_t rows_per_block,
+                              int rgroup, int rskip) {
   // block (64 cols x 4 row-lanes); grid (ceil(n/64), row_splits)
   __shared__ float red[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
   int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = std::min<int64_t>(rows, r0 + rows_per_block);
   float s = 0.f;
-  if (col < n) for (int64_t r = r0 + w; r < r1; r += 4) s += ld(x + r * ld_ + col);
+  if (col < n) for (int64_t r = r0 + w; r < r1; r += 4) {
+    int64_t pr = r; if (rgroup > 0) pr = r + (r / rgroup + 1) * (int64_t)rskip;
+    s += ld(x + pr * ld_ + col);
+  }
   red[w][threadIdx.x & 63] = s;
   __syncthreads();
   if (w == 0 && col < n) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 template <typename T>
-void k_colsum(spa3d_ctx* c, const T* x, int64_t rows, int n, int64_t ld_, float* out) {
+void k_colsum(spa3d_ctx* c, const T* x, int64_t rows, int n, int64_t ld_, float* out, int rgroup, int rskip) {
   if (c->dry || rows == 0) return;
   int64_t splits = std::max<int64_t>(1, std::min<int64_t>(cdiv(rows, 256), 1024 / std::max<int64_t>(1, cdiv(n, 64)) + 1));
   int64_t rpb = cdiv(rows, splits);
-  colsum_kernel<T><<<dim3((unsigned)cdiv(n, 64), (unsigned)cdiv(rows, rpb)), 256, 0, c->stream>>>(x, rows, n, ld_, out, rpb);
+  colsum_kernel<T><<<dim3((unsigned)cdiv(n, 64), (unsigned)cdiv(rows, rpb)), 256, 0, c->stream>>>(x, rows, n, ld_, out, rpb, rgroup, rskip);
   SPA_LAUNCH_CHECK(c);
 }
 
@@ -822,7 +826,7 @@ void k_uniform_noise(spa3d_ctx* c, float* out, int64_t n, uint32_t k0, uint32_t 
   template void k_softmax_bwd<T>(spa3d_ctx*, const T*, T*, int64_t, int);                                                              \
   template void k_sin_embed<T>(spa3d_ctx*, const float*, int64_t, int, int, float, T*);                                                \
   template void k_embed_tokens<T>(spa3d_ctx*, const float*, int64_t, int, int, float, T*);                                             \
-  template void k_colsum<T>(spa3d_ctx*, const T*, int64_t, int, int64_t, float*);                                                      \
+  template void k_colsum<T>(spa3d_ctx*, const T*, int64_t, int, int64_t, float*, int, int);                                                    \
   template void k_gelu<T>(spa3d_ctx*, const T*, T*, int64_t);                                                                          \
   template void k_add<T>(spa3d_ctx*, T*, const T*, int64_t);                                                                           \
   template void k_cast_from_f32<T>(spa3d_ctx*, const float*, T*, int64_t);                                                             \

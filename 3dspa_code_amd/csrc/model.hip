@@ -118,6 +118,7 @@ template <typename T> struct Net {
   Lin<T> tok, dino, depth, comp, decomp, qenc, pred;
   XfW<T> enc, t2l, dec, ro;
   const float *lat0, *readout; float *g_lat0, *g_readout;
+  void* zero_page = nullptr;
 
   Net(spa3d_ctx* c_, const float* P_, float* G_) : c(c_), g(c_->cfg), P(P_), G(G_) {
     for (auto& l : c->leaves) off[l.name] = l.offset;
@@ -166,6 +167,7 @@ template <typename T> struct Net {
   }
   // builds all shadows at the current arena position (re-done every call: 0.9 GB of traffic, << 1 ms)
   void pack() {
+    zero_page = c->ar.alloc(256); k_zero(c, zero_page, 256);
     const int d = g.track_token_dim, dl = g.encoder_latent_dim, dd = g.decoder_num_channels, nf = g.num_frequencies;
     lat0 = p("initializer/state_init"); g_lat0 = gr("initializer/state_init");
     readout = p("input_readout_token/state_init"); g_readout = gr("input_readout_token/state_init");
@@ -194,12 +196,12 @@ template <typename T> struct Net {
   }
   // Y[M,N] = epi(X[M,K] W + b) (+ residual)
   void lin_fwd(const Lin<T>& l, const T* X, void* Y, int64_t M, int epi = EPI_NONE, const T* residual = nullptr, int out_f32 = 0,
-               int accumulate = 0, int64_t ldx = 0, int64_t ldy = 0, int nb = 1, int64_t bX = 0, int64_t bY = 0) {
+               int accumulate = 0, int64_t ldx = 0, int64_t ldy = 0, int crow_group = 0, int crow_skip = 0) {
     GemmDesc d{};
     d.A = X; d.B = l.wn; d.C = Y; d.M = M; d.N = l.N; d.K = l.K;
     d.sAm = ldx ? ldx : l.K; d.sAk = 1; d.sBk = l.N; d.sBn = 1; d.sCm = ldy ? ldy : l.N;
     d.Bt = l.wt; d.ldBt = l.K;
-    d.nb1 = nb; d.bA1 = bX; d.bC1 = bY;
+    d.crow_group = crow_group; d.crow_skip = crow_skip;
     d.bias = l.bias; d.epi = epi; d.aux = residual; d.out_f32 = out_f32; d.accumulate = accumulate;
     gemm(d);
   }
@@ -214,15 +216,15 @@ template <typename T> struct Net {
     gemm(d);
   }
   // gw += X^T dY ; gb += colsum(dY)
-  void lin_bwd_w(const Lin<T>& l, const T* X, const T* dY, int64_t M, int64_t ldx = 0) {
+  void lin_bwd_w(const Lin<T>& l, const T* X, const T* dY, int64_t M, int64_t ldx = 0, int brow_group = 0, int brow_skip = 0) {
     for (int s = 0; s < l.nseg; ++s) {
       GemmDesc d{};
       d.A = X; d.B = dY + (int64_t)s * l.segw; d.C = l.gw[s]; d.M = l.K; d.N = l.segw; d.K = M;
       d.sAm = 1; d.sAk = ldx ? ldx : l.K; d.sBk = l.N; d.sBn = 1; d.sCm = l.segw;
-      d.out_f32 = 1; d.accumulate = 1;
+      d.out_f32 = 1; d.accumulate = 1; d.zero_page = zero_page; d.brow_group = brow_group; d.brow_skip = brow_skip;
       gemm(d);
     }
-    if (l.gb) k_colsum<T>(c, dY, M, l.N, l.N, l.gb);
+    if (l.gb) k_colsum<T>(c, dY, M, l.N, l.N, l.gb, brow_group, brow_skip);
   }
 
   // ------------------------------------------------------------------ attention core (attention.hip)
@@ -332,15 +334,15 @@ template <typename T> struct Net {
     k_embed_tokens<T>(c, tracks, nseq * T_, T_, nf, g.track_scale_factor, k.sinbuf);                 // 3d:126-134
     k.tok0 = alloc<T>(nseq * S * d);
     // rows 1..T of every sequence <- Dense(sin) [+ Dense(dino)] [+ Dense(depth)]                      3d:137-147
-    lin_fwd(tok, k.sinbuf, k.tok0 + d, T_, EPI_NONE, nullptr, 0, 0, 0, 0, (int)nseq, (int64_t)T_ * tok.K, (int64_t)S * d);
+    lin_fwd(tok, k.sinbuf, k.tok0, nseq * T_, EPI_NONE, nullptr, 0, 0, 0, 0, T_, 1);
     k.dino = nullptr; k.depthf = nullptr;
     if (g.dino_feature_dim > 0 && b->dino_features) {
       k.dino = (const T*)b->dino_features + b0 * k.N * T_ * g.dino_feature_dim;
-      lin_fwd(dino, (const T*)k.dino, k.tok0 + d, T_, EPI_NONE, nullptr, 0, 1, 0, 0, (int)nseq, (int64_t)T_ * dino.K, (int64_t)S * d);
+      lin_fwd(dino, (const T*)k.dino, k.tok0, nseq * T_, EPI_NONE, nullptr, 0, 1, 0, 0, T_, 1);
     }
     if (g.depth_feature_dim > 0 && b->depth_features) {
       k.depthf = (const T*)b->depth_features + b0 * k.N * T_ * g.depth_feature_dim;
-      lin_fwd(depth, (const T*)k.depthf, k.tok0 + d, T_, EPI_NONE, nullptr, 0, 1, 0, 0, (int)nseq, (int64_t)T_ * depth.K, (int64_t)S * d);
+      lin_fwd(depth, (const T*)k.depthf, k.tok0, nseq * T_, EPI_NONE, nullptr, 0, 1, 0, 0, T_, 1);
     }
     k_set_readout_rows<T>(c, k.tok0, readout, nseq, S, d);                                           // 3d:161-165
     k.km = alloc<float>(nseq * S);
@@ -489,11 +491,10 @@ template <typename T> struct Net {
     for (int i = (int)enc.blocks.size() - 1; i >= 0; --i)
       block_bwd(enc.blocks[i], k.enc_st[i], dtok, dtok, nseq, S, k.km, nullptr, 0, nullptr);
     k_bcast_grad<T>(c, dtok, d, nseq, (int64_t)S * d, g_readout);
-    T* dtokc = alloc<T>(nseq * T_ * d);
-    k_compact_tokens<T>(c, dtok, dtokc, nseq, S, d);
-    lin_bwd_w(tok, k.sinbuf, dtokc, nseq * T_);
-    if (k.dino) lin_bwd_w(dino, (const T*)k.dino, dtokc, nseq * T_);
-    if (k.depthf) lin_bwd_w(depth, (const T*)k.depthf, dtokc, nseq * T_);
+    // token rows 1..T of every sequence (row remap on the reduction index: no compaction copy)
+    lin_bwd_w(tok, k.sinbuf, dtok, nseq * T_, 0, T_, 1);
+    if (k.dino) lin_bwd_w(dino, (const T*)k.dino, dtok, nseq * T_, 0, T_, 1);
+    if (k.depthf) lin_bwd_w(depth, (const T*)k.depthf, dtok, nseq * T_, 0, T_, 1);
     c->ar.release(mk0);
   }
 };

@@ -48,6 +48,7 @@ int op_linear_bwd(OpCtx& c, const T* A, const T* B, const T* dC, T* dA, float* d
     GemmDesc d{};
     d.A = A; d.B = dC; d.C = dB; d.M = K; d.N = N; d.K = M; d.sAm = 1; d.sAk = K; d.sBk = N; d.sBn = 1; d.sCm = N;
     d.out_f32 = 1; d.accumulate = 1;
+    void* zp = c.alloc<char>(256); k_zero(&c, zp, 256); d.zero_page = zp;
     bool done = false;
     if constexpr (sizeof(T) == 2) { if (impl != 1) done = gemm_tn_bf16(&c, d); }
     if (!done) { if (impl == 2) return SPA3D_ERR_ARG; gemm_generic<T>(&c, d); }

@@ -192,3 +192,41 @@ def test_train_step_matches_oracle_adamw(spa3d):
   got = O.tree_flatten(st.params)
   for k, v in flatP.items():
     assert max_abs(got[k], v) < 2e-4, k  # three Adam steps at lr 1e-2: sign-like updates amplify tiny grad differences
+
+
+def test_cfg1_bf16_tiled_vs_generic_and_fp32(spa3d, monkeypatch):
+  """Full-size model at cfg#1 shapes in bf16: the tiled MFMA GEMMs / fused kernels (default) against the generic
+  kernels (SPA3D_GEMM_IMPL=1, SPA3D_ATTN_IMPL=1: same bf16 arithmetic, different accumulation order) and against
+  the fp32 path that test_cfg1_fp32_parity_1e4 pins to the oracle."""
+  cfg = O.Config(num_output_frames=24, use_dino=True, use_depth=True, dino_feature_dim=768, depth_feature_dim=1)
+  B, N, Q, T = 2, 64, 16, 24
+  batch = O.synthetic_batch(B, N, Q, T, seed=1234, dino_dim=768, depth_dim=1)
+  gb = batch_to(batch, 'cuda')
+  gb['dino_features'] = gb['dino_features'].bfloat16()
+  gb['depth_features'] = gb['depth_features'].bfloat16()
+  noise = _noise(B, cfg).cuda()
+  m_fast = product_model(spa3d, cfg, 'bf16')
+  params = m_fast.init(0, gb)['params']
+  _perturb(params)
+  ld_f, g_f, p_f = m_fast.loss_and_grads({'params': params}, gb, noise=noise, return_predictions=True)
+  g_fast = g_f.flat.clone()
+  monkeypatch.setenv('SPA3D_GEMM_IMPL', '1')
+  monkeypatch.setenv('SPA3D_ATTN_IMPL', '1')
+  m_gen = product_model(spa3d, cfg, 'bf16')
+  ld_g, g_g, p_g = m_gen.loss_and_grads({'params': params}, gb, noise=noise, return_predictions=True)
+  monkeypatch.delenv('SPA3D_GEMM_IMPL')
+  monkeypatch.delenv('SPA3D_ATTN_IMPL')
+  e = rel_err(p_f.tracks, p_g.tracks)
+  cos = float((g_fast.double() @ g_g.flat.double()) / (g_fast.double().norm() * g_g.flat.double().norm()))
+  print('bf16 tiled vs generic: tracks rel', e, 'grad cosine', cos)
+  assert e < 2e-2 and cos > 0.995
+  m32 = product_model(spa3d, cfg, 'fp32')
+  gb32 = dict(gb)
+  gb32['dino_features'] = gb['dino_features'].float()
+  gb32['depth_features'] = gb['depth_features'].float()
+  ld_32, g_32, p_32 = m32.loss_and_grads({'params': params}, gb32, noise=noise, return_predictions=True)
+  e32 = rel_err(p_f.tracks, p_32.tracks)
+  cos32 = float((g_fast.double() @ g_32.flat.double()) / (g_fast.double().norm() * g_32.flat.double().norm()))
+  print('bf16 tiled vs fp32: tracks rel', e32, 'loss', float(ld_f['total_loss']), float(ld_32['total_loss']), 'grad cosine', cos32)
+  assert e32 < 5e-2 and cos32 > 0.97
+  assert abs(float(ld_f['total_loss']) - float(ld_32['total_loss'])) < 5e-2 * abs(float(ld_32['total_loss']))

@@ -235,3 +235,57 @@ def test_adamw_step_matches_oracle(lib):
   gn = O.adamw_step(P, G, M, V, step=7, lr=3e-4)
   assert abs(float(scratch[0]) - gn) / gn < 1e-5
   assert max_abs(pd, P['a']) < 1e-6 and max_abs(md, M['a']) < 1e-7 and max_abs(vd, V['a']) < 1e-9
+
+
+# ------------------------------------------------------------------------------------------------ tiled bf16 kernels (impl=2)
+@pytest.mark.parametrize('M,N,K,act,res,bias', [(1000, 384, 256, 0, False, True), (4133, 2304, 384, 0, False, False),
+                                                (777, 1536, 384, 1, False, True), (2050, 384, 1536, 0, True, True),
+                                                (300, 600, 1280, 0, False, True), (129, 1280, 12352, 0, False, True)])
+def test_linear_tiled_nt(lib, M, N, K, act, res, bias):
+  g = torch.Generator().manual_seed(11)
+  A = torch.randn(M, K, generator=g).bfloat16()
+  B = (torch.randn(K, N, generator=g) / math.sqrt(K)).bfloat16()
+  bs = torch.randn(N, generator=g) if bias else None
+  R = torch.randn(M, N, generator=g).bfloat16() if res else None
+  Ad, Bd = A.cuda(), B.cuda()
+  bd = bs.cuda() if bias else None
+  Rd = R.cuda() if res else None
+  Cd = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
+  ws = _ws()
+  rc = lib.spa3d_op_linear(Ad.data_ptr(), Bd.data_ptr(), bd.data_ptr() if bias else None, Rd.data_ptr() if res else None, Cd.data_ptr(),
+                           M, N, K, act, BF16, 2, ws.data_ptr(), ws.numel(), _s())
+  assert rc == 0
+  ref = A.double() @ B.double()
+  if bias:
+    ref = ref + bs.double()
+  if act:
+    ref = O.gelu_tanh(ref)
+  if res:
+    ref = ref + R.double()
+  assert not torch.isnan(Cd.float()).any()
+  assert rel_err(Cd.float(), ref) < 4e-3  # bf16 output rounding only (2^-9); accumulation is fp32
+  assert max_abs(Cd.float(), ref) < 0.05 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize('M,N,K', [(5000, 384, 256), (3333, 2304, 384), (20000, 128, 64), (1100, 600, 1280), (257, 96, 512)])
+def test_linear_bwd_tiled(lib, M, N, K):
+  """dA = dC.B^T on the NT kernel (needs N % 64 == 0, else generic), dB = A^T.dC on the transposed-read TN kernel."""
+  g = torch.Generator().manual_seed(12)
+  A = torch.randn(M, K, generator=g).bfloat16()
+  B = (torch.randn(K, N, generator=g) / math.sqrt(K)).bfloat16()
+  dC = torch.randn(M, N, generator=g).bfloat16()
+  Ad, Bd, dCd = A.cuda(), B.cuda(), dC.cuda()
+  dA = torch.full((M, K), float('nan'), device='cuda', dtype=torch.bfloat16)
+  dB = torch.full((K, N), float('nan'), device='cuda')
+  ws = _ws()
+  impl_a = 2 if (N % 64 == 0 and M * K >= 128 * 128) else 0
+  rc = lib.spa3d_op_linear_bwd(Ad.data_ptr(), Bd.data_ptr(), dCd.data_ptr(), dA.data_ptr(), None, None, M, N, K, BF16, impl_a,
+                               ws.data_ptr(), ws.numel(), _s())
+  assert rc == 0
+  rc = lib.spa3d_op_linear_bwd(Ad.data_ptr(), Bd.data_ptr(), dCd.data_ptr(), None, dB.data_ptr(), None, M, N, K, BF16, 2,
+                               ws.data_ptr(), ws.numel(), _s())
+  assert rc == 0
+  assert rel_err(dA.float(), dC.double() @ B.double().T) < 4e-3
+  rB = A.double().T @ dC.double()
+  assert rel_err(dB, rB) < 1e-5  # exact bf16 products, fp32 accumulate + fp32 atomics
+  assert max_abs(dB, rB) < 1e-3 * float(rB.abs().max()) + 1e-4
