@@ -71,9 +71,9 @@ _SIGS = {
     'spa3d_op_layernorm_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     'spa3d_op_attention': (C.c_int, [C.c_void_p] * 3 + [C.c_int64] * 3 + [C.c_void_p] * 3 + [C.c_int64] + [C.c_int32] * 4
-                           + [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+                           + [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     'spa3d_op_attention_bwd': (C.c_int, [C.c_void_p] * 3 + [C.c_int64] * 3 + [C.c_void_p] * 3 + [C.c_int64]
-                               + [C.c_int32] * 4 + [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                               + [C.c_int32] * 4 + [C.c_void_p] * 8 + [C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
                                                                        C.c_void_p]),
 }
 

@@ -15,11 +15,11 @@
 
 template <typename T>
 void attention_fwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq,
-                   const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, T* o, int impl);
+                   const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, T* o, float* lse, int impl);
 template <typename T>
 void attention_bwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq,
-                   const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, const T* d_o, T* dq, T* dk, T* dv,
-                   float* dsq, float* dsk, int impl);
+                   const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, const T* o, const float* lse, const T* d_o,
+                   T* dq, T* dk, T* dv, float* dsq, float* dsk, int impl);
 
 static const float L1_WEIGHT = 5000.0f, BCE_WEIGHT = 1e-8f;  // train.py:96
 
@@ -108,7 +108,7 @@ template <typename T> struct BlockW {
 template <typename T> struct XfW { std::vector<BlockW<T>> blocks; const float* norm_enc; float* g_norm_enc; int d; };
 template <typename T> struct BlockStash {
   T *x, *nq, *qkv, *o, *a, *na, *hpre, *cq = nullptr, *ckv = nullptr, *co = nullptr;
-  float *st1, *st2;
+  float *st1, *st2, *lse = nullptr, *clse = nullptr;
 };
 
 template <typename T> struct Net {
@@ -229,12 +229,13 @@ template <typename T> struct Net {
 
   // ------------------------------------------------------------------ attention core (attention.hip)
   void attn_fwd(const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq, const float* sk,
-                const float* km, int64_t nseq, int Sq, int Sk, T* o) {
-    attention_fwd<T>(c, q, k, v, ldq, ldk, ldv, sq, sk, km, nseq, Sq, Sk, H, Dh, o, c->attn_impl);
+                const float* km, int64_t nseq, int Sq, int Sk, T* o, float* lse) {
+    attention_fwd<T>(c, q, k, v, ldq, ldk, ldv, sq, sk, km, nseq, Sq, Sk, H, Dh, o, lse, c->attn_impl);
   }
   void attn_bwd(const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq, const float* sk,
-                const float* km, int64_t nseq, int Sq, int Sk, const T* d_o, T* dq, T* dk, T* dv, float* dsq, float* dsk) {
-    attention_bwd<T>(c, q, k, v, ldq, ldk, ldv, sq, sk, km, nseq, Sq, Sk, H, Dh, d_o, dq, dk, dv, dsq, dsk, c->attn_impl);
+                const float* km, int64_t nseq, int Sq, int Sk, const T* o, const float* lse, const T* d_o, T* dq, T* dk, T* dv,
+                float* dsq, float* dsk) {
+    attention_bwd<T>(c, q, k, v, ldq, ldk, ldv, sq, sk, km, nseq, Sq, Sk, H, Dh, o, lse, d_o, dq, dk, dv, dsq, dsk, c->attn_impl);
   }
 
   // ------------------------------------------------------------------ ImprovedTransformerBlock (attention.py:67-108)
@@ -245,16 +246,16 @@ template <typename T> struct Net {
     k_layernorm<T>(c, x, w.norm_q, nq, st1, M, d);                                      // :76-78
     T* qkv = alloc<T>(M * 3 * E);
     lin_fwd(w.qkv, nq, qkv, M);                                                         // :154-173
-    T* o = alloc<T>(M * E);
-    attn_fwd(qkv, qkv + E, qkv + 2 * E, 3 * E, 3 * E, 3 * E, w.sq, w.sk, km, nseq, S, S, o);  // :166-175
+    T* o = alloc<T>(M * E); float* lse = alloc<float>(M * H * 2);
+    attn_fwd(qkv, qkv + E, qkv + 2 * E, 3 * E, 3 * E, 3 * E, w.sq, w.sk, km, nseq, S, S, o, lse);  // :166-175
     T* a = alloc<T>(M * d);
     lin_fwd(w.out, o, a, M, EPI_NONE, x);                                               // :178-183 + residual :79,90
-    T *cq = nullptr, *ckv = nullptr, *co = nullptr;
+    T *cq = nullptr, *ckv = nullptr, *co = nullptr; float* clse = nullptr;
     if (w.cross) {                                                                      // :92-100
       cq = alloc<T>(M * E); lin_fwd(w.cq, nq, cq, M);
       ckv = alloc<T>(nseq * Skv * 2 * E); lin_fwd(w.ckv, kv, ckv, nseq * Skv);
-      co = alloc<T>(M * E);
-      attn_fwd(cq, ckv, ckv + E, E, 2 * E, 2 * E, w.csq, w.csk, nullptr, nseq, S, Skv, co);
+      co = alloc<T>(M * E); clse = alloc<float>(M * H * 2);
+      attn_fwd(cq, ckv, ckv + E, E, 2 * E, 2 * E, w.csq, w.csk, nullptr, nseq, S, Skv, co, clse);
       lin_fwd(w.cout, co, a, M, EPI_NONE, a);
     }
     T* na = alloc<T>(M * d); float* st2 = alloc<float>(M * 2);
@@ -267,7 +268,7 @@ template <typename T> struct Net {
     lin_fwd(w.mlp_out, h, y, M, EPI_NONE, a);                                           // :107-108
     c->ar.release(mk2);
     if (st) { st->x = const_cast<T*>(x); st->nq = nq; st->qkv = qkv; st->o = o; st->a = a; st->na = na; st->hpre = hpre;
-              st->st1 = st1; st->st2 = st2; st->cq = cq; st->ckv = ckv; st->co = co; }
+              st->st1 = st1; st->st2 = st2; st->cq = cq; st->ckv = ckv; st->co = co; st->lse = lse; st->clse = clse; }
     else c->ar.release(mk);
   }
   // dy -> dx (dx may alias dy); dkv accumulated (T) if cross
@@ -291,8 +292,8 @@ template <typename T> struct Net {
     T* d_o = alloc<T>(M * E);
     lin_bwd_x(w.out, da, d_o, M);
     T* dqkv = alloc<T>(M * 3 * E);
-    attn_bwd(s.qkv, s.qkv + E, s.qkv + 2 * E, 3 * E, 3 * E, 3 * E, w.sq, w.sk, km, nseq, S, S, d_o, dqkv, dqkv + E, dqkv + 2 * E,
-             w.g_sq, w.g_sk);
+    attn_bwd(s.qkv, s.qkv + E, s.qkv + 2 * E, 3 * E, 3 * E, 3 * E, w.sq, w.sk, km, nseq, S, S, s.o, s.lse, d_o, dqkv, dqkv + E,
+             dqkv + 2 * E, w.g_sq, w.g_sk);
     lin_bwd_w(w.qkv, s.nq, dqkv, M);
     lin_bwd_x(w.qkv, dqkv, dnq, M);
     if (w.cross) {
@@ -300,7 +301,8 @@ template <typename T> struct Net {
       lin_bwd_x(w.cout, da, d_o, M);  // d_o := d co
       T* dcq = dqkv;                  // reuse [M,E]
       T* dckv = alloc<T>(nseq * Skv * 2 * E);
-      attn_bwd(s.cq, s.ckv, s.ckv + E, E, 2 * E, 2 * E, w.csq, w.csk, nullptr, nseq, S, Skv, d_o, dcq, dckv, dckv + E, w.g_csq, w.g_csk);
+      attn_bwd(s.cq, s.ckv, s.ckv + E, E, 2 * E, 2 * E, w.csq, w.csk, nullptr, nseq, S, Skv, s.co, s.clse, d_o, dcq, dckv, dckv + E,
+               w.g_csq, w.g_csk);
       // attn_bwd writes dq with stride ldq = E into dcq: dense [M,E]
       lin_bwd_w(w.cq, s.nq, dcq, M);
       lin_bwd_x(w.cq, dcq, dnq, M, nullptr, 1);

@@ -61,11 +61,11 @@ int op_linear_bwd(OpCtx& c, const T* A, const T* B, const T* dC, T* dA, float* d
 // attention front ends live in attention.hip
 template <typename T>
 void attention_fwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq,
-                   const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, T* o, int impl);
+                   const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, T* o, float* lse, int impl);
 template <typename T>
 void attention_bwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq,
-                   const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, const T* d_o, T* dq, T* dk, T* dv,
-                   float* dsq, float* dsk, int impl);
+                   const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, const T* o, const float* lse, const T* d_o,
+                   T* dq, T* dk, T* dv, float* dsq, float* dsk, int impl);
 
 extern "C" {
 
@@ -110,29 +110,30 @@ int spa3d_op_layernorm_bwd(const void* x, const float* scale, const float* stats
 
 int spa3d_op_attention(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* scale_q,
                        const float* scale_k, const float* keymask, int64_t nseq, int32_t Sq, int32_t Sk, int32_t H, int32_t Dh, void* o,
-                       int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream) {
+                       float* lse, int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream) {
   if (!q || !k || !v || !o || !scale_q || !scale_k || Dh > 128) return SPA3D_ERR_ARG;
   OpCtx c(stream, ws, ws_bytes);
   if (dtype == SPA3D_F32)
     attention_fwd<float>(&c, (const float*)q, (const float*)k, (const float*)v, ldq, ldk, ldv, scale_q, scale_k, keymask, nseq, Sq, Sk, H, Dh,
-                         (float*)o, impl);
+                         (float*)o, lse, impl);
   else
     attention_fwd<bf16_t>(&c, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, scale_q, scale_k, keymask, nseq, Sq, Sk, H,
-                          Dh, (bf16_t*)o, impl);
+                          Dh, (bf16_t*)o, lse, impl);
   return c.status();
 }
 int spa3d_op_attention_bwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* scale_q,
                            const float* scale_k, const float* keymask, int64_t nseq, int32_t Sq, int32_t Sk, int32_t H, int32_t Dh,
-                           const void* d_o, void* dq, void* dk, void* dv, float* dscale_q, float* dscale_k, int32_t dtype, int32_t impl,
+                           const void* o, const float* lse, const void* d_o, void* dq, void* dk, void* dv, float* dscale_q,
+                           float* dscale_k, int32_t dtype, int32_t impl,
                            void* ws, int64_t ws_bytes, void* stream) {
   if (!q || !k || !v || !d_o || !dq || !dk || !dv || !dscale_q || !dscale_k || Dh > 128) return SPA3D_ERR_ARG;
   OpCtx c(stream, ws, ws_bytes);
   if (dtype == SPA3D_F32)
     attention_bwd<float>(&c, (const float*)q, (const float*)k, (const float*)v, ldq, ldk, ldv, scale_q, scale_k, keymask, nseq, Sq, Sk, H, Dh,
-                         (const float*)d_o, (float*)dq, (float*)dk, (float*)dv, dscale_q, dscale_k, impl);
+                         (const float*)o, lse, (const float*)d_o, (float*)dq, (float*)dk, (float*)dv, dscale_q, dscale_k, impl);
   else
     attention_bwd<bf16_t>(&c, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, scale_q, scale_k, keymask, nseq, Sq, Sk, H,
-                          Dh, (const bf16_t*)d_o, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, dscale_q, dscale_k, impl);
+                          Dh, (const bf16_t*)o, lse, (const bf16_t*)d_o, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, dscale_q, dscale_k, impl);
   return c.status();
 }
 

@@ -124,6 +124,7 @@ class TrackAutoEncoder3D:
       raise ValueError(f'self.num_heads={self.num_heads} must divide self.qk_size={self.qkv_size}.')
     self._handles: Dict[Any, Any] = {}
     self._ws: Optional[torch.Tensor] = None
+    self._ws_cap = 0  # size of a budget-limited workspace (0: none / large enough for every request so far)
 
   # -------------------------------------------------------------------------------- handles / layout
   @property
@@ -309,8 +310,8 @@ class TrackAutoEncoder3D:
     want = lib.spa3d_workspace_bytes(h, B, max(N, 1), Q, max(T, 1), B, 1 if train else 0)
     floor = lib.spa3d_workspace_bytes(h, B, max(N, 1), Q, max(T, 1), 1, 1 if train else 0)
     have = self._ws.numel() if (self._ws is not None and self._ws.device == torch.device(device)) else 0
-    if have >= want:
-      return self._ws
+    if have >= want or (have >= floor and have >= self._ws_cap):
+      return self._ws  # big enough for the whole batch, or already as large as the memory budget allowed
     free, _total = torch.cuda.mem_get_info(device)
     budget = int((free + have) * self.workspace_fraction)
     size = min(want, max(budget, floor))
@@ -318,6 +319,7 @@ class TrackAutoEncoder3D:
       self._ws = None
       torch.cuda.empty_cache()
       self._ws = torch.empty(size, dtype=torch.uint8, device=device)
+      self._ws_cap = size if size < want else 0
     return self._ws
 
   # -------------------------------------------------------------------------------- public methods

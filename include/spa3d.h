@@ -172,11 +172,13 @@ int spa3d_op_layernorm_bwd(const void* x, const float* scale, const float* stats
 int spa3d_op_attention(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv,
                        const float* scale_q, const float* scale_k, const float* keymask,
                        int64_t nseq, int32_t Sq, int32_t Sk, int32_t H, int32_t Dh, void* o,
+                       float* lse /* [nseq,H,Sq,2] = (row max, log row sum); written by the fused kernel only; may be NULL */,
                        int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream);
 /* gradients of the above: dq,dk,dv dense-strided like q,k,v (same ld*); dscale_q/k f32[Dh] accumulated into */
 int spa3d_op_attention_bwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv,
                            const float* scale_q, const float* scale_k, const float* keymask,
                            int64_t nseq, int32_t Sq, int32_t Sk, int32_t H, int32_t Dh,
+                           const void* o, const float* lse /* forward outputs: needed by the fused kernel, NULL -> generic */,
                            const void* d_o, void* dq, void* dk, void* dv, float* dscale_q, float* dscale_k,
                            int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream);
 

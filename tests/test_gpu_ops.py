@@ -176,8 +176,8 @@ def test_attention_fwd_bwd_generic(lib, dtype, nseq, Sq, Sk, H, Dh, masked, pack
   o = torch.empty(nseq, Sq, E, device='cuda', dtype=dt)
   ws = _ws(512 << 20)
   rc = lib.spa3d_op_attention(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), ldq, ldk, ldv, sqd.data_ptr(), skd.data_ptr(),
-                              kmd.data_ptr() if masked else None, nseq, Sq, Sk, H, Dh, o.data_ptr(), dtype, 1, ws.data_ptr(), ws.numel(),
-                              _s())
+                              kmd.data_ptr() if masked else None, nseq, Sq, Sk, H, Dh, o.data_ptr(), None, dtype, 1, ws.data_ptr(),
+                              ws.numel(), _s())
   assert rc == 0
   qr = q.double().contiguous().requires_grad_(True)
   kr = k.double().contiguous().requires_grad_(True)
@@ -198,7 +198,7 @@ def test_attention_fwd_bwd_generic(lib, dtype, nseq, Sq, Sk, H, Dh, masked, pack
   dsq = torch.zeros(Dh, device='cuda')
   dsk = torch.zeros(Dh, device='cuda')
   rc = lib.spa3d_op_attention_bwd(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), ldq, ldk, ldv, sqd.data_ptr(), skd.data_ptr(),
-                                  kmd.data_ptr() if masked else None, nseq, Sq, Sk, H, Dh, dod.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                  kmd.data_ptr() if masked else None, nseq, Sq, Sk, H, Dh, None, None, dod.data_ptr(), dq.data_ptr(), dk.data_ptr(),
                                   dv.data_ptr(), dsq.data_ptr(), dsk.data_ptr(), dtype, 1, ws.data_ptr(), ws.numel(), _s())
   assert rc == 0
   if dtype == F32:
@@ -289,3 +289,54 @@ def test_linear_bwd_tiled(lib, M, N, K):
   rB = A.double().T @ dC.double()
   assert rel_err(dB, rB) < 1e-5  # exact bf16 products, fp32 accumulate + fp32 atomics
   assert max_abs(dB, rB) < 1e-3 * float(rB.abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize('nseq,S,H,masked', [(5, 25, 8, True), (3, 129, 8, False), (4, 151, 8, True), (2, 128, 8, False), (3, 40, 2, True)])
+def test_attention_fused_fwd_bwd(lib, nseq, S, H, masked):
+  """LDS-resident fused forward (impl=2) vs the fp64 oracle; packed q|k|v rows as the QKV projection writes them."""
+  Dh, E = 96, H * 96
+  g = torch.Generator().manual_seed(21)
+  qkv = torch.randn(nseq, S, 3 * E, generator=g).bfloat16()
+  sq = 1 + 0.2 * torch.randn(Dh, generator=g)
+  sk = 1 + 0.2 * torch.randn(Dh, generator=g)
+  km = None
+  if masked:
+    km = (torch.rand(nseq, S, generator=g) < 0.8).float()
+    km[:, 0] = 1.0
+    km[0, 1:] = 0.0
+  qkvd = qkv.cuda()
+  o = torch.full((nseq, S, E), float('nan'), device='cuda', dtype=torch.bfloat16)
+  lse = torch.zeros(nseq, H, S, 2, device='cuda')
+  ws = _ws(64 << 20)
+  sqd, skd = sq.cuda(), sk.cuda()
+  kmd = km.cuda() if masked else None
+  rc = lib.spa3d_op_attention(qkvd[..., :E].data_ptr(), qkvd[..., E:2 * E].data_ptr(), qkvd[..., 2 * E:].data_ptr(), 3 * E, 3 * E, 3 * E,
+                              sqd.data_ptr(), skd.data_ptr(), kmd.data_ptr() if masked else None, nseq, S, S, H, Dh, o.data_ptr(),
+                              lse.data_ptr(), BF16, 2, ws.data_ptr(), ws.numel(), _s())
+  assert rc == 0
+  qr = qkv[..., :E].double().contiguous().requires_grad_(True)
+  kr = qkv[..., E:2 * E].double().contiguous().requires_grad_(True)
+  vr = qkv[..., 2 * E:].double().contiguous().requires_grad_(True)
+  sqr, skr = sq.double().requires_grad_(True), sk.double().requires_grad_(True)
+  ref = _attn_ref(qr, kr, vr, sqr, skr, km, H, Dh)
+  assert not torch.isnan(o.float()).any()
+  e = rel_err(o.float(), ref.detach())
+  print('fused attention fwd rel err', e)
+  assert e < 2e-2
+  # fused backward (needs the forward's o and lse)
+  d_o = torch.randn(nseq, S, E, generator=g).bfloat16()
+  ref.backward(d_o.double())
+  dod = d_o.cuda()
+  dqkv = torch.full((nseq, S, 3 * E), float('nan'), device='cuda', dtype=torch.bfloat16)
+  dsq = torch.zeros(Dh, device='cuda')
+  dsk = torch.zeros(Dh, device='cuda')
+  rc = lib.spa3d_op_attention_bwd(qkvd[..., :E].data_ptr(), qkvd[..., E:2 * E].data_ptr(), qkvd[..., 2 * E:].data_ptr(), 3 * E, 3 * E,
+                                  3 * E, sqd.data_ptr(), skd.data_ptr(), kmd.data_ptr() if masked else None, nseq, S, S, H, Dh,
+                                  o.data_ptr(), lse.data_ptr(), dod.data_ptr(), dqkv[..., :E].data_ptr(), dqkv[..., E:2 * E].data_ptr(),
+                                  dqkv[..., 2 * E:].data_ptr(), dsq.data_ptr(), dsk.data_ptr(), BF16, 2, ws.data_ptr(), ws.numel(), _s())
+  assert rc == 0
+  assert not torch.isnan(dqkv.float()).any()
+  errs = [rel_err(dqkv[..., :E].float(), qr.grad), rel_err(dqkv[..., E:2 * E].float(), kr.grad), rel_err(dqkv[..., 2 * E:].float(), vr.grad),
+          rel_err(dsq, sqr.grad), rel_err(dsk, skr.grad)]
+  print('fused attention bwd rel errs dq dk dv dsq dsk', errs)
+  assert max(errs) < 3e-2
