@@ -140,6 +140,7 @@ struct GemmDesc {
   int64_t ldBt = 0;
   int32_t crow_group = 0, crow_skip = 0;  // C row m is stored at row m + (m/crow_group + 1)*crow_skip (token rows behind a readout row)
   int32_t brow_group = 0, brow_skip = 0;  // same remap on B's k index (dW over token rows that skip the readout row)
+  void* pre_out = nullptr;                // with EPI_GELU: the pre-activation (T, C layout) is stored here as well
   const void* zero_page = nullptr;        // >= 16 B of zeros (tiled TN kernel: rows past the end of the reduction)
 };
 

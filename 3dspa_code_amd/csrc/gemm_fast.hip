@@ -28,7 +28,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
 struct NtArgs {
   const bf16_t* A; const bf16_t* Bt; void* C;
   int64_t M; int N; int K; int64_t lda, ldb, ldc;
-  const float* bias; const bf16_t* aux; int epi; int out_f32; int accumulate; float alpha;
+  const float* bias; const bf16_t* aux; bf16_t* pre_out; int epi; int out_f32; int accumulate; float alpha;
   int tiles_m, tiles_n, crow_group, crow_skip;
 };
 
@@ -99,50 +99,72 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
     __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading `cur`
   }
 
-  // ---- epilogue: lane holds C[m = wm+16i+fr][n = wn+16j+4fq .. +3]
+  // ---- epilogue.  A lane holds C[m = wm+16i+fr][n = wn+16j+4fq .. +3]; the tile goes through LDS (f32, 16-B chunks XORed
+  // with the row so neither side conflicts badly) and leaves as whole 256-B row segments: 16-byte coalesced bias /
+  // residual / pre-activation / output accesses instead of 8-byte pieces scattered over 16 rows per instruction.
+  float* cs = (float*)smem;  // [128][128] f32 = the 64 KiB the K-loop no longer needs (last barrier already passed)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t gm = m0 + wm + i * 16 + fr;
-    if (gm >= g.M) continue;
-    int64_t crow = gm;
-    if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int gn = n0 + wn + j * 16 + fq * 4;
-      if (gn >= g.N) continue;  // N % 4 == 0 is required, so a 4-group is in or out as a whole
-      float v[4];
+      const int row = wm + i * 16 + fr, ch = (wn >> 2) + j * 4 + fq;
+      *(f32x4*)(cs + row * 128 + ((ch ^ (row & 31)) << 2)) = acc[i][j];
+    }
+  __syncthreads();
+  const int er = tid >> 4, ec = tid & 15;
+  const int gn = n0 + ec * 8;
+  if (gn >= g.N) return;  // N % 8 == 0: an 8-column group is in or out as a whole
+  float b8[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = g.alpha * acc[i][j][r];
-      if (g.bias) { const float4 b4 = *(const float4*)(g.bias + gn); v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
-      if (g.epi == EPI_GELU) {
+  for (int r = 0; r < 8; ++r) b8[r] = 0.f;
+  if (g.bias) { const float4 b0 = *(const float4*)(g.bias + gn), b1 = *(const float4*)(g.bias + gn + 4);
+    b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w; }
+#pragma unroll 2
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 16 + er;
+    const int64_t gm = m0 + row;
+    if (gm >= g.M) break;
+    int64_t crow = gm;
+    if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
+    const f32x4 v0 = *(const f32x4*)(cs + row * 128 + (((2 * ec) ^ (row & 31)) << 2));
+    const f32x4 v1 = *(const f32x4*)(cs + row * 128 + (((2 * ec + 1) ^ (row & 31)) << 2));
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+    for (int r = 0; r < 8; ++r) v[r] = g.alpha * v[r] + b8[r];
+    const int64_t ci = crow * g.ldc + gn;
+    if (g.pre_out) {
+      uint4 p4; unsigned* pp = (unsigned*)&p4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pp[r] = (unsigned)f2bf(v[2 * r]) | ((unsigned)f2bf(v[2 * r + 1]) << 16);
+      *(uint4*)(g.pre_out + ci) = p4;
+    }
+    if (g.epi == EPI_GELU) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_f(v[r]);
+    }
+    if (g.aux) {
+      const uint4 x4 = *(const uint4*)(g.aux + ci); const unsigned* xp = (const unsigned*)&x4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float xa = __uint_as_float(xp[r] << 16), xb = __uint_as_float(xp[r] & 0xffff0000u);
+        if (g.epi == EPI_MUL_GELU_GRAD) { v[2 * r] *= gelu_tanh_grad_f(xa); v[2 * r + 1] *= gelu_tanh_grad_f(xb); }
+        else { v[2 * r] += xa; v[2 * r + 1] += xb; }
       }
-      const int64_t ci = crow * g.ldc + gn;
-      if (g.aux) {
-        const u16x4 x4 = *(const u16x4*)(g.aux + ci);
-        if (g.epi == EPI_MUL_GELU_GRAD) {
+    }
+    if (g.out_f32) {
+      float4* cp = (float4*)((float*)g.C + ci);
+      if (g.accumulate) { const float4 o0 = cp[0], o1 = cp[1];
+        v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w; v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w; }
+      cp[0] = make_float4(v[0], v[1], v[2], v[3]); cp[1] = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      uint4* cp = (uint4*)((bf16_t*)g.C + ci);
+      if (g.accumulate) { const uint4 o4 = *cp; const unsigned* op = (const unsigned*)&o4;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
-        } else {
+        for (int r = 0; r < 4; ++r) { v[2 * r] += __uint_as_float(op[r] << 16); v[2 * r + 1] += __uint_as_float(op[r] & 0xffff0000u); } }
+      uint4 o4; unsigned* op = (unsigned*)&o4;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += bf2f(x4[r]);
-        }
-      }
-      if (g.out_f32) {
-        float4* cp = (float4*)((float*)g.C + ci);
-        if (g.accumulate) { const float4 o = *cp; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
-        *cp = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        u16x4* cp = (u16x4*)((bf16_t*)g.C + ci);
-        if (g.accumulate) { const u16x4 o = *cp;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += bf2f(o[r]); }
-        u16x4 o4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o4[r] = f2bf(v[r]);
-        *cp = o4;
-      }
+      for (int r = 0; r < 4; ++r) op[r] = (unsigned)f2bf(v[2 * r]) | ((unsigned)f2bf(v[2 * r + 1]) << 16);
+      *cp = o4;
     }
   }
 }
@@ -156,15 +178,16 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   else if (d.sBk == 1) { Bt = (const bf16_t*)d.B; ldb = d.sBn; }
   else return false;
   if (d.sAk != 1 || d.nb1 != 1 || d.nb2 != 1 || d.atomic) return false;
-  if (d.K % 64 || d.N % 4 || d.M < 1 || d.K < 64) return false;
-  if (d.sAm % 8 || ldb % 8 || d.sCm % 4 || !aligned16(d.A) || !aligned16(Bt) || !aligned16(d.C)) return false;
+  if (d.K % 64 || d.N % 8 || d.M < 1 || d.K < 64) return false;
+  if (d.sAm % 8 || ldb % 8 || d.sCm % 8 || !aligned16(d.A) || !aligned16(Bt) || !aligned16(d.C)) return false;
   if (d.aux && (!aligned16(d.aux) || d.out_f32)) return false;
   if (d.bias && !aligned16(d.bias)) return false;
+  if (d.pre_out && (!aligned16(d.pre_out) || d.out_f32)) return false;
   if ((int64_t)d.M * d.N < 128 * 128) return false;  // tiny problems: the generic kernel has less tail waste
   if (c->dry) return true;
   NtArgs g;
   g.A = (const bf16_t*)d.A; g.Bt = Bt; g.C = d.C; g.M = d.M; g.N = d.N; g.K = d.K; g.lda = d.sAm; g.ldb = ldb; g.ldc = d.sCm;
-  g.bias = d.bias; g.aux = (const bf16_t*)d.aux; g.epi = d.epi; g.out_f32 = d.out_f32; g.accumulate = d.accumulate; g.alpha = d.alpha;
+  g.bias = d.bias; g.aux = (const bf16_t*)d.aux; g.pre_out = (bf16_t*)d.pre_out; g.epi = d.epi; g.out_f32 = d.out_f32; g.accumulate = d.accumulate; g.alpha = d.alpha;
   g.tiles_m = (int)((d.M + 127) / 128); g.tiles_n = (d.N + 127) / 128;
   g.crow_group = d.crow_group; g.crow_skip = d.crow_skip;
   const int64_t blocks = (int64_t)((g.tiles_m + 7) / 8) * 8 * g.tiles_n;
@@ -256,34 +279,46 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
     if (t + 1 < nt) stage(cur ^ 1, t + 1);
     const char* sa = smem + cur * 32768;
     const char* sb = sa + 16384;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      uint2 a_lo[2], a_hi[2], b_lo[2], b_hi[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ch = (wi + i * 32) / 8 + cbase;
-        a_lo[i] = ds_read_tr16_b64(sa + tr_off(ks * 16 + kq, ch) + 8 * (lp & 1));
-        a_hi[i] = ds_read_tr16_b64(sa + tr_off(ks * 16 + kq + 4, ch) + 8 * (lp & 1));
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int ch = (wn + j * 32) / 8 + cbase;
-        b_lo[j] = ds_read_tr16_b64(sb + tr_off(ks * 16 + kq, ch) + 8 * (lp & 1));
-        b_hi[j] = ds_read_tr16_b64(sb + tr_off(ks * 16 + kq + 4, ch) + 8 * (lp & 1));
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs below the wait (cdna_hip_programming.md rule 18)
+    // fragments of k-step ks+1 are requested before the MFMAs of k-step ks issue (two register sets, static indices)
+    uint2 fa[2][4], fb[2][4];  // [set][i*2 + {lo,hi}]
+    auto load_frags = [&](int set, int ks) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const uint4 au = make_uint4(a_lo[i].x, a_lo[i].y, a_hi[i].x, a_hi[i].y);
+        const int cha = (wi + i * 32) / 8 + cbase, chb = (wn + i * 32) / 8 + cbase;
+        fa[set][i * 2] = ds_read_tr16_b64(sa + tr_off(ks * 16 + kq, cha) + 8 * (lp & 1));
+        fa[set][i * 2 + 1] = ds_read_tr16_b64(sa + tr_off(ks * 16 + kq + 4, cha) + 8 * (lp & 1));
+        fb[set][i * 2] = ds_read_tr16_b64(sb + tr_off(ks * 16 + kq, chb) + 8 * (lp & 1));
+        fb[set][i * 2 + 1] = ds_read_tr16_b64(sb + tr_off(ks * 16 + kq + 4, chb) + 8 * (lp & 1));
+      }
+    };
+    auto mma = [&](int set) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint4 au = make_uint4(fa[set][i * 2].x, fa[set][i * 2].y, fa[set][i * 2 + 1].x, fa[set][i * 2 + 1].y);
         const bf16x8 af = __builtin_bit_cast(bf16x8, au);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const uint4 bu = make_uint4(b_lo[j].x, b_lo[j].y, b_hi[j].x, b_hi[j].y);
+          const uint4 bu = make_uint4(fb[set][j * 2].x, fb[set][j * 2].y, fb[set][j * 2 + 1].x, fb[set][j * 2 + 1].y);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bu), acc[i][j], 0, 0, 0);
         }
       }
-    }
+    };
+    load_frags(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // MFMAs stay below the wait (cdna_hip_programming.md rule 18)
+    load_frags(1, 1);
+    mma(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(0, 2);
+    mma(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(1, 3);
+    mma(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1);
     __syncthreads();
   }
   if (nt == 0) return;

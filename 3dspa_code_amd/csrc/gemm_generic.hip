@@ -23,6 +23,7 @@ struct GemmArgs {
   float alpha; const float* bias; int epi; const void* aux; int aux_is_residual; int out_f32; int accumulate; int atomic;
   int tiles_m, tiles_n, ksplit; int64_t kchunk;
   int crow_group, crow_skip, brow_group, brow_skip;
+  void* pre_out;
 };
 
 template <typename T>
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs g) {
         if (g.bias && ks == 0) v += g.bias[gn];
         int64_t crow = gm; if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
         const int64_t ci = coff + crow * g.sCm + gn;
+        if (g.pre_out) st((T*)g.pre_out + ci, v);
         if (g.epi == EPI_GELU) v = gelu_tanh_f(v);
         if (g.aux) {
           float x = ld((const T*)g.aux + ci);
@@ -164,7 +166,7 @@ void gemm_generic(spa3d_ctx* c, const GemmDesc& d) {
   g.nb2 = d.nb2; g.bA1 = d.bA1; g.bA2 = d.bA2; g.bB1 = d.bB1; g.bB2 = d.bB2; g.bC1 = d.bC1; g.bC2 = d.bC2;
   g.alpha = d.alpha; g.bias = d.bias; g.epi = d.epi; g.aux = d.aux; g.aux_is_residual = d.aux_is_residual;
   g.out_f32 = d.out_f32; g.accumulate = d.accumulate; g.atomic = 0;
-  g.crow_group = d.crow_group; g.crow_skip = d.crow_skip; g.brow_group = d.brow_group; g.brow_skip = d.brow_skip;
+  g.crow_group = d.crow_group; g.crow_skip = d.crow_skip; g.brow_group = d.brow_group; g.brow_skip = d.brow_skip; g.pre_out = d.pre_out;
   g.tiles_m = (int)((d.M + 63) / 64); g.tiles_n = (d.N + 63) / 64;
   int64_t nbatch = (int64_t)d.nb1 * d.nb2;
   int64_t blocks = nbatch * g.tiles_m * g.tiles_n;

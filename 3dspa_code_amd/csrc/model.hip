@@ -107,7 +107,7 @@ template <typename T> struct BlockW {
 };
 template <typename T> struct XfW { std::vector<BlockW<T>> blocks; const float* norm_enc; float* g_norm_enc; int d; };
 template <typename T> struct BlockStash {
-  T *x, *nq, *qkv, *o, *a, *na, *hpre, *cq = nullptr, *ckv = nullptr, *co = nullptr;
+  T *x, *nq, *qkv, *o, *a, *na, *hpre, *h, *cq = nullptr, *ckv = nullptr, *co = nullptr;
   float *st1, *st2, *lse = nullptr, *clse = nullptr;
 };
 
@@ -196,12 +196,12 @@ template <typename T> struct Net {
   }
   // Y[M,N] = epi(X[M,K] W + b) (+ residual)
   void lin_fwd(const Lin<T>& l, const T* X, void* Y, int64_t M, int epi = EPI_NONE, const T* residual = nullptr, int out_f32 = 0,
-               int accumulate = 0, int64_t ldx = 0, int64_t ldy = 0, int crow_group = 0, int crow_skip = 0) {
+               int accumulate = 0, int64_t ldx = 0, int64_t ldy = 0, int crow_group = 0, int crow_skip = 0, T* pre_out = nullptr) {
     GemmDesc d{};
     d.A = X; d.B = l.wn; d.C = Y; d.M = M; d.N = l.N; d.K = l.K;
     d.sAm = ldx ? ldx : l.K; d.sAk = 1; d.sBk = l.N; d.sBn = 1; d.sCm = ldy ? ldy : l.N;
     d.Bt = l.wt; d.ldBt = l.K;
-    d.crow_group = crow_group; d.crow_skip = crow_skip;
+    d.crow_group = crow_group; d.crow_skip = crow_skip; d.pre_out = pre_out;
     d.bias = l.bias; d.epi = epi; d.aux = residual; d.out_f32 = out_f32; d.accumulate = accumulate;
     gemm(d);
   }
@@ -260,14 +260,10 @@ template <typename T> struct Net {
     }
     T* na = alloc<T>(M * d); float* st2 = alloc<float>(M * 2);
     k_layernorm<T>(c, a, w.norm_attn, na, st2, M, d);                                   // :103-105
-    T* hpre = alloc<T>(M * w.mlp);
-    lin_fwd(w.mlp_in, na, hpre, M);                                                     // :106
-    int64_t mk2 = c->ar.mark();
-    T* h = alloc<T>(M * w.mlp);
-    k_gelu<T>(c, hpre, h, M * w.mlp);
+    T* hpre = alloc<T>(M * w.mlp); T* h = alloc<T>(M * w.mlp);
+    lin_fwd(w.mlp_in, na, h, M, EPI_GELU, nullptr, 0, 0, 0, 0, 0, 0, hpre);             // :106  h = gelu(hpre), both kept for the backward
     lin_fwd(w.mlp_out, h, y, M, EPI_NONE, a);                                           // :107-108
-    c->ar.release(mk2);
-    if (st) { st->x = const_cast<T*>(x); st->nq = nq; st->qkv = qkv; st->o = o; st->a = a; st->na = na; st->hpre = hpre;
+    if (st) { st->x = const_cast<T*>(x); st->nq = nq; st->qkv = qkv; st->o = o; st->a = a; st->na = na; st->hpre = hpre; st->h = h;
               st->st1 = st1; st->st2 = st2; st->cq = cq; st->ckv = ckv; st->co = co; st->lse = lse; st->clse = clse; }
     else c->ar.release(mk);
   }
@@ -276,10 +272,8 @@ template <typename T> struct Net {
                  int Skv, T* dkv) {
     const int64_t M = nseq * S; const int d = w.d;
     int64_t mk = c->ar.mark();
-    T* h = alloc<T>(M * w.mlp);
-    k_gelu<T>(c, s.hpre, h, M * w.mlp);
-    lin_bwd_w(w.mlp_out, h, dy, M);
-    T* dh = h;  // reuse: dh = dy Wout^T * gelu'(hpre)
+    lin_bwd_w(w.mlp_out, s.h, dy, M);
+    T* dh = alloc<T>(M * w.mlp);  // dh = dy Wout^T * gelu'(hpre)
     lin_bwd_x(w.mlp_out, dy, dh, M, s.hpre);
     lin_bwd_w(w.mlp_in, s.na, dh, M);
     T* dna = alloc<T>(M * d);
