@@ -30,6 +30,30 @@ def create_learning_rate_schedule(base_lr: float, warmup_steps: int, total_steps
   return schedule
 
 
+def global_visible_count(visible: torch.Tensor, group=None) -> float:
+  """max(sum(query_tracks_visible) over ALL ranks, 1): both loss terms divide by the batch-global visible count
+  (train.py:111-113,119-121), so under data parallelism it is one scalar all-reduce BEFORE the backward."""
+  s = visible.to(torch.float32).sum()
+  if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+  return max(float(s.item()), 1.0)
+
+
+def allreduce_flat_(flat: torch.Tensor, bucket_elems: int, group=None, extra=()):
+  """In-place SUM all-reduce of a flat buffer in a few large buckets (RCCL ring: per-link xGMI bound, so few and
+  large), all in flight together; `extra` small tensors ride along.  Returns when every bucket has been reduced."""
+  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    return
+  works = []
+  n = flat.numel()
+  for s in range(0, n, bucket_elems):
+    works.append(dist.all_reduce(flat[s:s + bucket_elems], op=dist.ReduceOp.SUM, group=group, async_op=True))
+  for t in extra:
+    works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True))
+  for w in works:
+    w.wait()
+
+
 class TrainState:
   """create_model_state + train_step of train.py:132-187,217-260 for model_type='3dspa'."""
 
@@ -55,32 +79,13 @@ class TrainState:
     self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
     self.bucket_elems = max(1, grad_bucket_bytes // 4)
 
-  def _global_denominator(self, batch) -> float:
-    """Both loss terms divide by the batch-GLOBAL visible count (train.py:111-113,119-121): one scalar all-reduce."""
-    s = batch['query_tracks_visible'].to(torch.float32).sum()
-    if self.world > 1:
-      dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.pg)
-    return max(float(s.item()), 1.0)
-
-  def _allreduce_grads(self, loss3):
-    """Gradient SUM all-reduce (the per-rank gradients already carry the global 1/denominator), a few large
-    buckets so RCCL's ring runs near the per-link xGMI rate; loss numerators ride along."""
-    if self.world == 1:
-      return
-    n = self.grads.numel()
-    works = []
-    for s in range(0, n, self.bucket_elems):
-      works.append(dist.all_reduce(self.grads[s:s + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-    works.append(dist.all_reduce(loss3, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-    for w in works:
-      w.wait()
-
   def train_step(self, batch, discretize: bool = True, noise=None):
-    denom = self._global_denominator(batch) if self.world > 1 else 0.0
+    denom = global_visible_count(batch['query_tracks_visible'], self.pg) if self.world > 1 else 0.0
     ld, _, _ = self.model.loss_and_grads(self.params, batch, grads_flat=self.grads, accumulate=False, denom=denom,
                                          discretize=discretize, noise=noise)
     l3 = torch.stack([ld['total_loss'], ld['position_loss'], ld['visible_loss']])
-    self._allreduce_grads(l3)
+    # the per-rank gradients and loss terms already carry the global 1/denominator -> plain SUM over ranks
+    allreduce_flat_(self.grads, self.bucket_elems, self.pg, extra=(l3,))
     lr = self.schedule(self.step)
     _lib.check(_lib.load().spa3d_adamw_step(self.flat.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                             self.flat.numel(), lr, self.step, self.clip, self.b1, self.b2, self.eps, self.wd,

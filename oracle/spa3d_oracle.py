@@ -343,11 +343,13 @@ def sigmoid_binary_cross_entropy(logits, labels):
   return -labels * ls(logits) - (1.0 - labels) * ls(-logits)
 
 
-def compute_loss_3d(predictions: Results, targets, l1_weight=5000.0, bce_weight=1e-8):
+def compute_loss_3d(predictions: Results, targets, l1_weight=5000.0, bce_weight=1e-8, denom=None):
+  """train.py:96-129.  `denom` (not in the reference): an externally supplied max(sum(visible),1) -- the batch-GLOBAL
+  count when the batch is sharded over data-parallel ranks; None = this batch's own, as the reference computes it."""
   tt, tv = targets['query_tracks'], targets['query_tracks_visible']
   vm = tv.to(predictions.tracks.dtype)
   pos = (torch.abs(predictions.tracks - tt) * vm).sum(dim=(-2, -1))
-  denom = torch.clamp(vm.sum(), min=1.0)
+  denom = torch.clamp(vm.sum(), min=1.0) if denom is None else denom
   pos = pos.sum() / denom
   vis = sigmoid_binary_cross_entropy(predictions.visible_logits, vm).sum() / denom
   return {'total_loss': l1_weight * pos + bce_weight * vis, 'position_loss': pos, 'visible_loss': vis}
@@ -520,12 +522,12 @@ def adamw_step(params_flat, grads_flat, m, v, step, lr, clip=1.0, wd=0.01, b1=0.
   return gn
 
 
-def loss_and_grads(model: TrackAutoEncoder3D, params: Params, batch, discretize=True, noise=None):
+def loss_and_grads(model: TrackAutoEncoder3D, params: Params, batch, discretize=True, noise=None, denom=None):
   """jax.value_and_grad(loss_fn)(params) equivalent via torch autograd on the restated graph."""
   flat = tree_flatten(params)
   leaves = {k: v.detach().clone().requires_grad_(True) for k, v in flat.items()}
   preds = model(tree_unflatten(leaves), batch, discretize=discretize, noise=noise)
-  ld = compute_loss_3d(preds, batch)
+  ld = compute_loss_3d(preds, batch, denom=denom)
   ld['total_loss'].backward()
   grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
   return {k: v.detach() for k, v in ld.items()}, preds, grads
