@@ -221,10 +221,13 @@ __device__ __forceinline__ int tr_off(int row, int ch) { return 256 * row + 16 *
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 64 rows x 256 B | B 64 rows x 256 B]
-  int bid = blockIdx.x;
-  const int tn = bid % g.tiles_n; bid /= g.tiles_n;
-  const int ti = bid % g.tiles_i; bid /= g.tiles_i;
-  const int sp = bid;
+  // XCD-aware id: blocks b, b+8, .. share an XCD (and its L2); all output tiles of one M-split read the same rows of
+  // A and B, so they are given to ONE XCD, adjacent in dispatch order -> the rows come from HBM once, not once per XCD
+  const int xcd = blockIdx.x & 7; int j = blockIdx.x >> 3;
+  const int ntile = g.tiles_i * g.tiles_n;
+  const int sp = (j / ntile) * 8 + xcd; j %= ntile;
+  if (sp >= g.splits) return;
+  const int tn = j % g.tiles_n, ti = j / g.tiles_n;
   const int i0 = ti * 128, n0 = tn * 128;
   const int64_t mbeg = (int64_t)sp * g.rows_per_split;
   int64_t mend = mbeg + g.rows_per_split; if (mend > g.M) mend = g.M;
@@ -360,7 +363,7 @@ bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d) {
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
   ProfScope ps(c, PROF_GEMM_TN, 2.0 * (double)M * Ki * N, ((double)M * Ki + (double)M * N) * 2.0 + (double)Ki * N * 4.0 * splits);
-  gemm_tn_kernel<<<(unsigned)(tiles * splits), 256, 65536, c->stream>>>(g);
+  gemm_tn_kernel<<<(unsigned)(tiles * ((splits + 7) / 8 * 8)), 256, 65536, c->stream>>>(g);
   SPA_LAUNCH_CHECK(c);
   return true;
 }
