@@ -197,3 +197,11 @@ void k_loss_finalize(spa3d_ctx*, const float* sums, const float* denom_dev, floa
 void k_adamw(spa3d_ctx*, float* p, const float* g, float* m, float* v, int64_t n, float lr, int64_t step, float clip, float b1, float b2,
              float eps, float wd, float* scratch);
 void k_uniform_noise(spa3d_ctx*, float* out, int64_t n, uint32_t k0, uint32_t k1);
+// single-query attention of the pruned last block (kernels.hip)
+template <typename T> void k_attn_q1_fwd(spa3d_ctx*, const T* q0, int64_t ldq0, const T* k, const T* v, int64_t ldk, int64_t ldv,
+                                         const float* sq, const float* sk, const float* km, int64_t nseq, int S, int H, int Dh, T* o0,
+                                         float* p0);
+template <typename T> void k_attn_q1_bwd(spa3d_ctx*, const T* q0, int64_t ldq0, const T* k, const T* v, int64_t ldk, int64_t ldv,
+                                         const float* sq, const float* sk, const float* km, int64_t nseq, int S, int H, int Dh,
+                                         const float* p0, const T* d_o0, T* dq0, T* dk, T* dv, float* dsq, float* dsk);
+template <typename T> void k_add_rows_strided(spa3d_ctx*, T* dst, const T* src, int64_t dst_stride_rows, int64_t n, int d);

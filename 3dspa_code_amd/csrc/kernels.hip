@@ -979,3 +979,253 @@ void k_uniform_noise(spa3d_ctx* c, float* out, int64_t n, uint32_t k0, uint32_t 
   template void k_loss_bwd<T>(spa3d_ctx*, const float*, int64_t, int, const float*, const float*, const float*, float, float, T*);
 INST(float)
 INST(bf16_t)
+
+// ---------------------------------------------------------------------------------------------
+// Single-query attention (last block of the track encoder / readout stack: only token 0 leaves the stack,
+// track_autoencoder_3d.py:187-188,286, so only its query row is needed; K/V still come from every token).
+// One wave per (sequence, head).  lane = 4*kgrp + part: 16 keys per pass, each key row split over 4 lanes
+// (Dh/4 contiguous channels each).  RMSNorm of q/k, 1/sqrt(Dh), key mask, softmax and PV fused; the
+// probabilities are kept (fp32, tiny) for the backward.
+// ---------------------------------------------------------------------------------------------
+#define Q1_MAXIT 20   // S <= 320
+#define Q1_MAXC 32    // Dh/4 <= 32
+template <typename T>
+__global__ __launch_bounds__(256) void attn_q1_fwd_kernel(const T* __restrict__ q0, int64_t ldq0, const T* __restrict__ k, const T* __restrict__ v,
+                                                          int64_t ldk, int64_t ldv, const float* __restrict__ sq, const float* __restrict__ sk,
+                                                          const float* __restrict__ km, int64_t nprob, int S, int H, int Dh,
+                                                          T* __restrict__ o0, float* __restrict__ p0) {
+  const int lane = threadIdx.x & 63, part = lane & 3, kg = lane >> 2;
+  const int C = Dh / 4, c0 = part * C;
+  const float alpha = rsqrtf((float)Dh);
+  const int nit = (S + 15) / 16;
+  for (int64_t prob = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); prob < nprob; prob += (int64_t)gridDim.x * 4) {
+    const int64_t seq = prob / H; const int h = (int)(prob - seq * H);
+    float qh[Q1_MAXC]; float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) { qh[j] = ld(q0 + seq * ldq0 + h * Dh + c0 + j); ss += qh[j] * qh[j]; }
+    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64);
+    const float rq = rsqrtf(ss / Dh + 1e-6f);
+#pragma unroll
+    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) qh[j] *= rq * sq[c0 + j];
+    float sc[Q1_MAXIT]; float m = -3.4028234663852886e38f;
+#pragma unroll
+    for (int it = 0; it < Q1_MAXIT; ++it) {
+      sc[it] = -__builtin_inff();
+      if (it < nit) {
+        const int key = it * 16 + kg;
+        if (key < S) {
+          const T* kr = k + (seq * S + key) * ldk + h * Dh + c0;
+          float kv_[Q1_MAXC]; float ks = 0.f;
+#pragma unroll
+          for (int j = 0; j < Q1_MAXC; ++j) if (j < C) { kv_[j] = ld(kr + j); ks += kv_[j] * kv_[j]; }
+          ks += __shfl_xor(ks, 1, 64); ks += __shfl_xor(ks, 2, 64);
+          const float rk = rsqrtf(ks / Dh + 1e-6f);
+          float d = 0.f;
+#pragma unroll
+          for (int j = 0; j < Q1_MAXC; ++j) if (j < C) d += qh[j] * kv_[j] * rk * sk[c0 + j];
+          d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64);
+          float lg = d * alpha;
+          if (km && km[seq * S + key] == 0.f) lg = -3.4028234663852886e38f;
+          sc[it] = lg; m = fmaxf(m, lg);
+        } else {  // keep the 4-lane shuffles convergent for absent keys
+          float z = 0.f; z += __shfl_xor(z, 1, 64); z += __shfl_xor(z, 2, 64); z += __shfl_xor(z, 1, 64); z += __shfl_xor(z, 2, 64);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int it = 0; it < Q1_MAXIT; ++it) if (it < nit) { sc[it] = expf(sc[it] - m); l += sc[it]; }
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) l += __shfl_xor(l, o, 64);
+    const float inv = 1.f / l;
+    float acc[Q1_MAXC];
+#pragma unroll
+    for (int j = 0; j < Q1_MAXC; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int it = 0; it < Q1_MAXIT; ++it)
+      if (it < nit) {
+        const int key = it * 16 + kg;
+        if (key < S) {
+          const float p = sc[it] * inv;
+          if (part == 0) p0[prob * S + key] = p;
+          const T* vr = v + (seq * S + key) * ldv + h * Dh + c0;
+#pragma unroll
+          for (int j = 0; j < Q1_MAXC; ++j) if (j < C) acc[j] += p * ld(vr + j);
+        }
+      }
+#pragma unroll
+    for (int j = 0; j < Q1_MAXC; ++j)
+      if (j < C) {
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) acc[j] += __shfl_xor(acc[j], o, 64);
+      }
+    if (kg == 0) {
+#pragma unroll
+      for (int j = 0; j < Q1_MAXC; ++j) if (j < C) st(o0 + seq * (int64_t)H * Dh + h * Dh + c0 + j, acc[j]);
+    }
+  }
+}
+template <typename T>
+void k_attn_q1_fwd(spa3d_ctx* c, const T* q0, int64_t ldq0, const T* k, const T* v, int64_t ldk, int64_t ldv, const float* sq, const float* sk,
+                   const float* km, int64_t nseq, int S, int H, int Dh, T* o0, float* p0) {
+  if (c->dry || nseq == 0) return;
+  const int64_t nprob = nseq * H;
+  unsigned g = (unsigned)std::min<int64_t>(cdiv(nprob, 4), 8192);
+  attn_q1_fwd_kernel<T><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, Dh, o0, p0);
+  SPA_LAUNCH_CHECK(c);
+}
+
+// backward of the above: dq0 [nseq, H*Dh]; dk, dv for EVERY key row (overwritten); scale gradients accumulated.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ q0, int64_t ldq0, const T* __restrict__ k, const T* __restrict__ v,
+                                                          int64_t ldk, int64_t ldv, const float* __restrict__ sq, const float* __restrict__ sk,
+                                                          const float* __restrict__ km, int64_t nprob, int S, int H, int Dh,
+                                                          const float* __restrict__ p0, const T* __restrict__ d_o0, T* __restrict__ dq0,
+                                                          T* __restrict__ dk, T* __restrict__ dv, float* __restrict__ dsq, float* __restrict__ dsk) {
+  __shared__ float red[2][4 * Q1_MAXC];
+  const int lane = threadIdx.x & 63, part = lane & 3, kg = lane >> 2;
+  const int C = Dh / 4, c0 = part * C;
+  const float alpha = rsqrtf((float)Dh);
+  const int nit = (S + 15) / 16;
+  float dsq_acc[Q1_MAXC], dsk_acc[Q1_MAXC];
+#pragma unroll
+  for (int j = 0; j < Q1_MAXC; ++j) { dsq_acc[j] = 0.f; dsk_acc[j] = 0.f; }
+  for (int64_t prob = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); prob < nprob; prob += (int64_t)gridDim.x * 4) {
+    const int64_t seq = prob / H; const int h = (int)(prob - seq * H);
+    float xq[Q1_MAXC], qh[Q1_MAXC], dout[Q1_MAXC]; float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < Q1_MAXC; ++j)
+      if (j < C) { xq[j] = ld(q0 + seq * ldq0 + h * Dh + c0 + j); ss += xq[j] * xq[j]; dout[j] = ld(d_o0 + seq * (int64_t)H * Dh + h * Dh + c0 + j); }
+    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64);
+    const float rq = rsqrtf(ss / Dh + 1e-6f);
+#pragma unroll
+    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) { xq[j] *= rq; qh[j] = xq[j] * sq[c0 + j]; }
+    // pass 1: dp_k = dO . V_k ; sum_k p_k dp_k
+    float dp[Q1_MAXIT]; float pd = 0.f;
+#pragma unroll
+    for (int it = 0; it < Q1_MAXIT; ++it) {
+      dp[it] = 0.f;
+      if (it < nit) {
+        const int key = it * 16 + kg;
+        float d = 0.f;
+        if (key < S) {
+          const T* vr = v + (seq * S + key) * ldv + h * Dh + c0;
+#pragma unroll
+          for (int j = 0; j < Q1_MAXC; ++j) if (j < C) d += dout[j] * ld(vr + j);
+        }
+        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64);
+        dp[it] = d;
+        if (key < S && part == 0) pd += p0[prob * S + key] * d;
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) pd += __shfl_xor(pd, o, 64);
+    // pass 2: per key dv, dk (through the RMSNorm), and the dq^ accumulation
+    float dqh[Q1_MAXC];
+#pragma unroll
+    for (int j = 0; j < Q1_MAXC; ++j) dqh[j] = 0.f;
+#pragma unroll
+    for (int it = 0; it < Q1_MAXIT; ++it)
+      if (it < nit) {
+        const int key = it * 16 + kg;
+        const bool valid = key < S;
+        float xk[Q1_MAXC]; float ks = 0.f, p = 0.f; bool keep = true;
+        const int64_t roff = valid ? (seq * S + key) : (seq * S);
+        if (valid) { p = p0[prob * S + key]; keep = !(km && km[seq * S + key] == 0.f); }
+#pragma unroll
+        for (int j = 0; j < Q1_MAXC; ++j) if (j < C) { xk[j] = ld(k + roff * ldk + h * Dh + c0 + j); ks += xk[j] * xk[j]; }
+        ks += __shfl_xor(ks, 1, 64); ks += __shfl_xor(ks, 2, 64);
+        const float rk = rsqrtf(ks / Dh + 1e-6f);
+        const float ds = keep ? p * (dp[it] - pd) * alpha : 0.f;  // where() passes no gradient to masked logits
+        float gx = 0.f;
+#pragma unroll
+        for (int j = 0; j < Q1_MAXC; ++j)
+          if (j < C) {
+            xk[j] *= rk;                                  // x^ of the key row
+            dqh[j] += ds * xk[j] * sk[c0 + j];            // dq^ += ds * k^
+            gx += ds * qh[j] * sk[c0 + j] * xk[j];        // g = dk^ * s_k ; dk^ = ds * q^
+          }
+        gx += __shfl_xor(gx, 1, 64); gx += __shfl_xor(gx, 2, 64);
+        gx /= Dh;
+        if (valid) {
+#pragma unroll
+          for (int j = 0; j < Q1_MAXC; ++j)
+            if (j < C) {
+              const float dkh = ds * qh[j];
+              st(dk + roff * ldk + h * Dh + c0 + j, rk * (dkh * sk[c0 + j] - xk[j] * gx));
+              st(dv + roff * ldv + h * Dh + c0 + j, p * dout[j]);
+              dsk_acc[j] += dkh * xk[j];
+            }
+        }
+      }
+    float gq = 0.f;
+#pragma unroll
+    for (int j = 0; j < Q1_MAXC; ++j)
+      if (j < C) {
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) dqh[j] += __shfl_xor(dqh[j], o, 64);
+        gq += dqh[j] * sq[c0 + j] * xq[j];
+      }
+    gq += __shfl_xor(gq, 1, 64); gq += __shfl_xor(gq, 2, 64);
+    gq /= Dh;
+    if (kg == 0) {
+#pragma unroll
+      for (int j = 0; j < Q1_MAXC; ++j)
+        if (j < C) {
+          st(dq0 + seq * (int64_t)H * Dh + h * Dh + c0 + j, rq * (dqh[j] * sq[c0 + j] - xq[j] * gq));
+          dsq_acc[j] += dqh[j] * xq[j];
+        }
+    }
+  }
+  // flush: sum over the 16 key groups (dsk) / take group 0 (dsq), then over the 4 waves, one atomic per channel per block
+  for (int t = threadIdx.x; t < 2 * 4 * Q1_MAXC; t += 256) ((float*)red)[t] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < Q1_MAXC; ++j)
+    if (j < C) {
+      float a = dsk_acc[j];
+#pragma unroll
+      for (int o = 4; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+      if (kg == 0) { atomicAdd(&red[1][part * Q1_MAXC + j], a); atomicAdd(&red[0][part * Q1_MAXC + j], dsq_acc[j]); }
+    }
+  __syncthreads();
+  for (int t = threadIdx.x; t < Dh; t += 256) {
+    const int pt = t / C, j = t - pt * C;
+    atomicAdd(dsq + t, red[0][pt * Q1_MAXC + j]);
+    atomicAdd(dsk + t, red[1][pt * Q1_MAXC + j]);
+  }
+}
+template <typename T>
+void k_attn_q1_bwd(spa3d_ctx* c, const T* q0, int64_t ldq0, const T* k, const T* v, int64_t ldk, int64_t ldv, const float* sq, const float* sk,
+                   const float* km, int64_t nseq, int S, int H, int Dh, const float* p0, const T* d_o0, T* dq0, T* dk, T* dv, float* dsq,
+                   float* dsk) {
+  if (c->dry || nseq == 0) return;
+  const int64_t nprob = nseq * H;
+  unsigned g = (unsigned)std::min<int64_t>(cdiv(nprob, 4), 2048);
+  attn_q1_bwd_kernel<T><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, Dh, p0, d_o0, dq0, dk, dv, dsq, dsk);
+  SPA_LAUNCH_CHECK(c);
+}
+// dst[i*stride_rows][:] += src[i][:]
+template <typename T>
+__global__ void add_rows_strided_kernel(T* __restrict__ dst, const T* __restrict__ src, int64_t drows, int64_t n, int d) {
+  const int64_t tot = n * d;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    int64_t r = i / d; int j = (int)(i - r * d);
+    T* p = dst + r * drows * d + j;
+    st(p, ld(p) + ld(src + i));
+  }
+}
+template <typename T> void k_add_rows_strided(spa3d_ctx* c, T* dst, const T* src, int64_t drows, int64_t n, int d) {
+  if (c->dry || n == 0) return;
+  add_rows_strided_kernel<T><<<GRID1D(n * d, 256), 256, 0, c->stream>>>(dst, src, drows, n, d); SPA_LAUNCH_CHECK(c);
+}
+#define INST_Q1(T)                                                                                                                     \
+  template void k_attn_q1_fwd<T>(spa3d_ctx*, const T*, int64_t, const T*, const T*, int64_t, int64_t, const float*, const float*,       \
+                                 const float*, int64_t, int, int, int, T*, float*);                                                     \
+  template void k_attn_q1_bwd<T>(spa3d_ctx*, const T*, int64_t, const T*, const T*, int64_t, int64_t, const float*, const float*,       \
+                                 const float*, int64_t, int, int, int, const float*, const T*, T*, T*, T*, float*, float*);             \
+  template void k_add_rows_strided<T>(spa3d_ctx*, T*, const T*, int64_t, int64_t, int);
+INST_Q1(float)
+INST_Q1(bf16_t)

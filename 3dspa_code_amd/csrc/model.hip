@@ -95,6 +95,7 @@ template <typename T> struct Lin {
   T* wt = nullptr;            // [N][K]  (Y = X . W with K contiguous)
   const float* bias = nullptr;
   int K = 0, N = 0, nseg = 1, segw = 0;
+  int64_t ldn = 0;            // row stride of wn (== N except for column sub-views of a fused matrix)
   const float* src[3] = {nullptr, nullptr, nullptr};  // f32 leaves [K][segw]
   float* gw[3] = {nullptr, nullptr, nullptr};         // f32 grads  [K][segw]
   float* gb = nullptr;
@@ -129,7 +130,7 @@ template <typename T> struct Net {
   float* gr(const std::string& n) { return G ? G + off.at(n) : nullptr; }
 
   Lin<T> make_lin(std::initializer_list<std::string> kernels, const std::string& bias, int K, int segw) {
-    Lin<T> l; l.K = K; l.segw = segw; l.nseg = (int)kernels.size(); l.N = segw * l.nseg;
+    Lin<T> l; l.K = K; l.segw = segw; l.nseg = (int)kernels.size(); l.N = segw * l.nseg; l.ldn = l.N;
     int i = 0;
     for (auto& k : kernels) { l.src[i] = p(k); l.gw[i] = gr(k); ++i; }
     if (!bias.empty()) { l.bias = p(bias); l.gb = gr(bias); }
@@ -137,6 +138,13 @@ template <typename T> struct Net {
     for (int s = 0; s < l.nseg; ++s)
       k_pack<T>(c, l.src[s], segw, K, segw, l.wn + (int64_t)s * segw, l.N, l.wt + (int64_t)s * segw * K, K);
     return l;
+  }
+  // columns [seg0*segw, (seg0+nseg)*segw) of a fused matrix as a Lin of its own (no bias)
+  static Lin<T> sub_lin(const Lin<T>& l, int seg0, int nseg) {
+    Lin<T> r = l; r.nseg = nseg; r.N = nseg * l.segw; r.bias = nullptr; r.gb = nullptr;
+    r.wn = l.wn + (int64_t)seg0 * l.segw; r.wt = l.wt + (int64_t)seg0 * l.segw * l.K;
+    for (int i = 0; i < 3; ++i) { r.src[i] = i < nseg ? l.src[seg0 + i] : nullptr; r.gw[i] = i < nseg ? l.gw[seg0 + i] : nullptr; }
+    return r;
   }
   XfW<T> make_xf(const std::string& name, int d, int mlp, int L, int kv) {
     XfW<T> x; x.d = d;
@@ -199,18 +207,18 @@ template <typename T> struct Net {
                int accumulate = 0, int64_t ldx = 0, int64_t ldy = 0, int crow_group = 0, int crow_skip = 0, T* pre_out = nullptr) {
     GemmDesc d{};
     d.A = X; d.B = l.wn; d.C = Y; d.M = M; d.N = l.N; d.K = l.K;
-    d.sAm = ldx ? ldx : l.K; d.sAk = 1; d.sBk = l.N; d.sBn = 1; d.sCm = ldy ? ldy : l.N;
+    d.sAm = ldx ? ldx : l.K; d.sAk = 1; d.sBk = l.ldn; d.sBn = 1; d.sCm = ldy ? ldy : l.N;
     d.Bt = l.wt; d.ldBt = l.K;
     d.crow_group = crow_group; d.crow_skip = crow_skip; d.pre_out = pre_out;
     d.bias = l.bias; d.epi = epi; d.aux = residual; d.out_f32 = out_f32; d.accumulate = accumulate;
     gemm(d);
   }
   // dX[M,K] (op)= dY[M,N] W^T, optionally * gelu'(pre)
-  void lin_bwd_x(const Lin<T>& l, const T* dY, T* dX, int64_t M, const T* gelu_pre = nullptr, int accumulate = 0) {
+  void lin_bwd_x(const Lin<T>& l, const T* dY, T* dX, int64_t M, const T* gelu_pre = nullptr, int accumulate = 0, int64_t lddx = 0) {
     GemmDesc d{};
     d.A = dY; d.B = l.wn; d.C = dX; d.M = M; d.N = l.K; d.K = l.N;
-    d.sAm = l.N; d.sAk = 1; d.sBk = 1; d.sBn = l.N; d.sCm = l.K;
-    d.Bt = l.wn; d.ldBt = l.N;
+    d.sAm = l.N; d.sAk = 1; d.sBk = 1; d.sBn = l.ldn; d.sCm = lddx ? lddx : l.K;
+    d.Bt = l.wn; d.ldBt = l.ldn;
     if (gelu_pre) { d.epi = EPI_MUL_GELU_GRAD; d.aux = gelu_pre; }
     d.accumulate = accumulate;
     gemm(d);
@@ -307,12 +315,70 @@ template <typename T> struct Net {
     c->ar.release(mk);
   }
 
+
+  // ------------------------------------------------------------------ last block of a stack whose output is token 0 only
+  // (track_autoencoder_3d.py:187-188, 286).  K/V (and LN1) still cover every token; the query, attention output,
+  // out-projection, LN2 and MLP are needed for row 0 of each sequence only: 25 % of a full block's GEMM work.
+  struct LastStash { T *x, *nq, *kv, *q0, *o0, *x0, *a0, *na0, *hpre0, *h0; float *st1, *st2, *p0; };
+  void block_fwd_last(const BlockW<T>& w, const T* x, T* y0, int64_t nseq, int S, const float* km, LastStash* st) {
+    const int64_t M = nseq * S; const int d = w.d;
+    const int64_t mk = c->ar.mark();
+    const Lin<T> wq = sub_lin(w.qkv, 0, 1), wkv = sub_lin(w.qkv, 1, 2);
+    T* nq = alloc<T>(M * d); float* st1 = alloc<float>(M * 2);
+    k_layernorm<T>(c, x, w.norm_q, nq, st1, M, d);
+    T* kv = alloc<T>(M * 2 * E);
+    lin_fwd(wkv, nq, kv, M);
+    T* q0 = alloc<T>(nseq * E);
+    lin_fwd(wq, nq, q0, nseq, EPI_NONE, nullptr, 0, 0, (int64_t)S * d);          // rows 0 of every sequence
+    T* o0 = alloc<T>(nseq * E); float* p0 = alloc<float>(nseq * H * S);
+    k_attn_q1_fwd<T>(c, q0, E, kv, kv + E, 2 * E, 2 * E, w.sq, w.sk, km, nseq, S, H, Dh, o0, p0);
+    T* x0 = alloc<T>(nseq * d);
+    k_gather_rows<T>(c, x, S, x0, nseq, d);
+    T* a0 = alloc<T>(nseq * d);
+    lin_fwd(w.out, o0, a0, nseq, EPI_NONE, x0);
+    T* na0 = alloc<T>(nseq * d); float* st2 = alloc<float>(nseq * 2);
+    k_layernorm<T>(c, a0, w.norm_attn, na0, st2, nseq, d);
+    T* hpre0 = alloc<T>(nseq * w.mlp); T* h0 = alloc<T>(nseq * w.mlp);
+    lin_fwd(w.mlp_in, na0, h0, nseq, EPI_GELU, nullptr, 0, 0, 0, 0, 0, 0, hpre0);
+    lin_fwd(w.mlp_out, h0, y0, nseq, EPI_NONE, a0);
+    if (st) { st->x = const_cast<T*>(x); st->nq = nq; st->kv = kv; st->q0 = q0; st->o0 = o0; st->x0 = x0; st->a0 = a0; st->na0 = na0;
+              st->hpre0 = hpre0; st->h0 = h0; st->st1 = st1; st->st2 = st2; st->p0 = p0; }
+    else c->ar.release(mk);
+  }
+  // dy0 [nseq,d] -> dx [nseq*S, d]
+  void block_bwd_last(const BlockW<T>& w, const LastStash& s, const T* dy0, T* dx, int64_t nseq, int S, const float* km) {
+    const int64_t M = nseq * S; const int d = w.d;
+    const int64_t mk = c->ar.mark();
+    const Lin<T> wq = sub_lin(w.qkv, 0, 1), wkv = sub_lin(w.qkv, 1, 2);
+    lin_bwd_w(w.mlp_out, s.h0, dy0, nseq);
+    T* dh = alloc<T>(nseq * w.mlp);
+    lin_bwd_x(w.mlp_out, dy0, dh, nseq, s.hpre0);
+    lin_bwd_w(w.mlp_in, s.na0, dh, nseq);
+    T* dna = alloc<T>(nseq * d);
+    lin_bwd_x(w.mlp_in, dh, dna, nseq);
+    T* da0 = alloc<T>(nseq * d);
+    k_layernorm_bwd<T>(c, s.a0, w.norm_attn, s.st2, dna, da0, w.g_norm_attn, nseq, d, dy0);
+    lin_bwd_w(w.out, s.o0, da0, nseq);
+    T* d_o0 = alloc<T>(nseq * E);
+    lin_bwd_x(w.out, da0, d_o0, nseq);
+    T* dq0 = alloc<T>(nseq * E); T* dkv = alloc<T>(M * 2 * E);
+    k_attn_q1_bwd<T>(c, s.q0, E, s.kv, s.kv + E, 2 * E, 2 * E, w.sq, w.sk, km, nseq, S, H, Dh, s.p0, d_o0, dq0, dkv, dkv + E, w.g_sq, w.g_sk);
+    lin_bwd_w(wkv, s.nq, dkv, M);
+    lin_bwd_w(wq, s.nq, dq0, nseq, (int64_t)S * d);
+    T* dnq = alloc<T>(M * d);
+    lin_bwd_x(wkv, dkv, dnq, M);
+    lin_bwd_x(wq, dq0, dnq, nseq, nullptr, 1, (int64_t)S * d);                    // += into rows 0
+    k_layernorm_bwd<T>(c, s.x, w.norm_q, s.st1, dnq, dx, w.g_norm_q, M, d, nullptr);
+    k_add_rows_strided<T>(c, dx, da0, S, nseq, d);                                 // residual path of token 0
+    c->ar.release(mk);
+  }
+
   // ------------------------------------------------------------------ per-chunk state
   struct Chunk {
     int64_t Bc, nseq; int N, Q, T_, S;
     // encoder
     T* sinbuf; const void* dino; const void* depthf; float* km; T* tok0; std::vector<BlockStash<T>> enc_st; T* enc_last; T* r0; float* st_r0;
-    T* enc_out;
+    T* enc_out; LastStash enc_lst, ro_lst;
     // t2l
     T* lat_in; std::vector<BlockStash<T>> t2l_st; T* t2l_last; float* st_t2l; T* t2l_n; float* latents;  // [Bc,L,Ld] f32
     // decode
@@ -344,17 +410,18 @@ template <typename T> struct Net {
     k.km = alloc<float>(nseq * S);
     k_keymask(c, b->support_tracks_visible + b0 * k.N * T_, b->boundary_frame + b0, nseq, k.N, T_, k.km);  // 3d:167-180 (R2,R3)
     const T* x = k.tok0;
-    k.enc_st.resize(enc.blocks.size());
+    const int nenc = (int)enc.blocks.size();
+    k.enc_st.resize(nenc);
     T* pp[2] = {nullptr, nullptr};
-    if (!train) { pp[0] = alloc<T>(nseq * S * d); pp[1] = alloc<T>(nseq * S * d); }
-    for (size_t i = 0; i < enc.blocks.size(); ++i) {
+    if (!train && nenc > 1) { pp[0] = alloc<T>(nseq * S * d); if (nenc > 2) pp[1] = alloc<T>(nseq * S * d); }
+    for (int i = 0; i + 1 < nenc; ++i) {
       T* y = train ? alloc<T>(nseq * S * d) : pp[i & 1];
       block_fwd(enc.blocks[i], x, y, nseq, S, k.km, nullptr, 0, train ? &k.enc_st[i] : nullptr);
       x = y;
     }
     k.enc_last = const_cast<T*>(x);
     k.r0 = alloc<T>(nseq * d); k.st_r0 = alloc<float>(nseq * 2); k.enc_out = alloc<T>(nseq * d);
-    k_gather_rows<T>(c, x, S, k.r0, nseq, d);                                                        // 3d:187-188
+    block_fwd_last(enc.blocks[nenc - 1], x, k.r0, nseq, S, k.km, train ? &k.enc_lst : nullptr);     // token 0 only: 3d:187-188
     k_layernorm<T>(c, k.r0, enc.norm_enc, k.enc_out, k.st_r0, nseq, d);                              // attention.py:49-51 (row 0 only)
     // L1-L3
     const int L = g.num_latent_tokens, dl = g.encoder_latent_dim;
@@ -406,17 +473,18 @@ template <typename T> struct Net {
     k.seq0 = alloc<T>(nq * S * dd);
     k_assemble_readout<T>(c, k.qtok, k.latd, k.qframe, k.Bc, k.Q, L, Cl, dd, k.seq0);
     x = k.seq0;
-    k.ro_st.resize(ro.blocks.size());
+    const int nro = (int)ro.blocks.size();
+    k.ro_st.resize(nro);
     T* pp[2] = {nullptr, nullptr};
-    if (!train) { pp[0] = alloc<T>(nq * S * dd); pp[1] = alloc<T>(nq * S * dd); }
-    for (size_t i = 0; i < ro.blocks.size(); ++i) {
+    if (!train && nro > 1) { pp[0] = alloc<T>(nq * S * dd); if (nro > 2) pp[1] = alloc<T>(nq * S * dd); }
+    for (int i = 0; i + 1 < nro; ++i) {
       T* y = train ? alloc<T>(nq * S * dd) : pp[i & 1];
       block_fwd(ro.blocks[i], x, y, nq, S, nullptr, nullptr, 0, train ? &k.ro_st[i] : nullptr);
       x = y;
     }
     k.ro_last = const_cast<T*>(x);
     k.q0 = alloc<T>(nq * dd); k.st_q0 = alloc<float>(nq * 2); k.q0n = alloc<T>(nq * dd);
-    k_gather_rows<T>(c, x, S, k.q0, nq, dd);                                                          // 3d:286
+    block_fwd_last(ro.blocks[nro - 1], x, k.q0, nq, S, nullptr, train ? &k.ro_lst : nullptr);       // token 0 only: 3d:286
     k_layernorm<T>(c, k.q0, ro.norm_enc, k.q0n, k.st_q0, nq, dd);
     k.head = alloc<float>(nq * 4 * g.num_output_frames);
     lin_fwd(pred, k.q0n, k.head, nq, EPI_NONE, nullptr, 1);                                           // 3d:287
@@ -443,9 +511,9 @@ template <typename T> struct Net {
       k_layernorm_bwd<T>(c, k.q0, ro.norm_enc, k.st_q0, dq0n, dq0, ro.g_norm_enc, nq, dd, nullptr);
       T* dqtok = alloc<T>(nq * dd);
       T* dseq = alloc<T>(nq * S * dd);
-      k_zero(c, dseq, nq * S * dd * (int64_t)sizeof(T));  // only token 0 leaves the readout stack (3d:286)
-      k_scatter_rows<T>(c, dq0, dseq, S, nq, dd);
-      for (int i = (int)ro.blocks.size() - 1; i >= 0; --i)
+      const int nro = (int)ro.blocks.size();
+      block_bwd_last(ro.blocks[nro - 1], k.ro_lst, dq0, dseq, nq, S, nullptr);
+      for (int i = nro - 2; i >= 0; --i)
         block_bwd(ro.blocks[i], k.ro_st[i], dseq, dseq, nq, S, nullptr, nullptr, 0, nullptr);
       k_assemble_readout_bwd<T>(c, dseq, k.qframe, k.Bc, k.Q, L, Cl, dd, dqtok, dlatd32);
       lin_bwd_w(qenc, k.sin2, dqtok, nq);
@@ -482,9 +550,9 @@ template <typename T> struct Net {
     T* dr0 = alloc<T>(nseq * d);
     k_layernorm_bwd<T>(c, k.r0, enc.norm_enc, k.st_r0, denc_out, dr0, enc.g_norm_enc, nseq, d, nullptr);
     T* dtok = alloc<T>(nseq * S * d);
-    k_zero(c, dtok, nseq * S * d * (int64_t)sizeof(T));  // only the readout token leaves the stack (3d:187-188)
-    k_scatter_rows<T>(c, dr0, dtok, S, nseq, d);
-    for (int i = (int)enc.blocks.size() - 1; i >= 0; --i)
+    const int nenc = (int)enc.blocks.size();
+    block_bwd_last(enc.blocks[nenc - 1], k.enc_lst, dr0, dtok, nseq, S, k.km);
+    for (int i = nenc - 2; i >= 0; --i)
       block_bwd(enc.blocks[i], k.enc_st[i], dtok, dtok, nseq, S, k.km, nullptr, 0, nullptr);
     k_bcast_grad<T>(c, dtok, d, nseq, (int64_t)S * d, g_readout);
     // token rows 1..T of every sequence (row remap on the reduction index: no compaction copy)
