@@ -42,36 +42,45 @@ constexpr int DH = 96, ROWB = DH * 2;  // 192-byte LDS rows
 
 // stage S rows of [*, 96] bf16 (row stride ld elements) into LDS rows of 192 B; 4 threads per row, 24 elements each.
 // NORM: per-row RMSNorm * scale (attention.py:167) before the bf16 round, as the unfused path stores it.
-template <bool NORM>
+template <bool NORM, int NP>
 __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, int64_t ld_, int S, int S_pad, const float* __restrict__ scale,
                                            char* lds) {
-  const int part = threadIdx.x & 3;
-  for (int row = threadIdx.x >> 2; row < S_pad; row += 64) {
-    u16x8 x[3];
+  const int part = threadIdx.x & 3, r0 = threadIdx.x >> 2;
+  u16x8 x[NP][3];
+  // every global load of this matrix is issued before the first use: one memory latency per matrix, not one per 64 rows
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const int row = r0 + 64 * ps;
     if (row < S) {
       const u16x8* p = (const u16x8*)(src + (int64_t)row * ld_ + part * 24);
-      x[0] = p[0]; x[1] = p[1]; x[2] = p[2];
+      x[ps][0] = p[0]; x[ps][1] = p[1]; x[ps][2] = p[2];
     } else {
 #pragma unroll
       for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[c][j] = 0;
+        for (int j = 0; j < 8; ++j) x[ps][c][j] = 0;
     }
+  }
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const int row = r0 + 64 * ps;
     if (NORM) {
       float f[24]; float ss = 0.f;
 #pragma unroll
       for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { f[c * 8 + j] = bf2f(x[c][j]); ss += f[c * 8 + j] * f[c * 8 + j]; }
+        for (int j = 0; j < 8; ++j) { f[c * 8 + j] = bf2f(x[ps][c][j]); ss += f[c * 8 + j] * f[c * 8 + j]; }
       ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64);
       const float r = rsqrtf(ss / DH + 1e-6f);
 #pragma unroll
       for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[c][j] = f2bf(f[c * 8 + j] * r * scale[part * 24 + c * 8 + j]);
+        for (int j = 0; j < 8; ++j) x[ps][c][j] = f2bf(f[c * 8 + j] * r * scale[part * 24 + c * 8 + j]);
     }
-    u16x8* d = (u16x8*)(lds + row * ROWB + part * 48);
-    d[0] = x[0]; d[1] = x[1]; d[2] = x[2];
+    if (row < S_pad) {
+      u16x8* d = (u16x8*)(lds + row * ROWB + part * 48);
+      d[0] = x[ps][0]; d[1] = x[ps][1]; d[2] = x[ps][2];
+    }
   }
 }
 
@@ -85,8 +94,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs g) {
   const int S = g.S, E = g.H * DH;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fq = lane >> 4;
 
-  stage_rows<true>(g.k + seq * S * g.ldk + h * DH, g.ldk, S, S_pad, g.sk, Ks);
-  stage_rows<false>(g.v + seq * S * g.ldv + h * DH, g.ldv, S, S_pad, nullptr, Vs);
+  constexpr int NP = (S_pad + 63) / 64;
+  stage_rows<true, NP>(g.k + seq * S * g.ldk + h * DH, g.ldk, S, S_pad, g.sk, Ks);
+  stage_rows<false, NP>(g.v + seq * S * g.ldv + h * DH, g.ldv, S, S_pad, nullptr, Vs);
   for (int t = tid; t < S_pad; t += 256) {
     float b = 0.f;
     if (t >= S) b = -__builtin_inff();                           // padding key: weight exactly 0
@@ -264,32 +274,42 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs g) {
   for (int64_t prob = blockIdx.x; prob < g.nprob; prob += gridDim.x) {
     const int64_t seq = prob / g.H; const int h = (int)(prob - seq * g.H);
     __syncthreads();  // previous problem's LDS reads are done
-    stage_rows<true>(g.q + seq * S * g.ldq + h * DH, g.ldq, S, S_pad, g.sq, Qs);
-    stage_rows<true>(g.k + seq * S * g.ldk + h * DH, g.ldk, S, S_pad, g.sk, Ks);
-    stage_rows<false>(g.v + seq * S * g.ldv + h * DH, g.ldv, S, S_pad, nullptr, Vs);
-    {  // dO rows + delta = rowsum(dO o O)
-      const int part = tid & 3;
-      for (int row = tid >> 2; row < S_pad; row += 64) {
-        u16x8 x[3]; float dsum = 0.f;
+    constexpr int NP = (S_pad + 63) / 64;
+    stage_rows<true, NP>(g.q + seq * S * g.ldq + h * DH, g.ldq, S, S_pad, g.sq, Qs);
+    stage_rows<true, NP>(g.k + seq * S * g.ldk + h * DH, g.ldk, S, S_pad, g.sk, Ks);
+    stage_rows<false, NP>(g.v + seq * S * g.ldv + h * DH, g.ldv, S, S_pad, nullptr, Vs);
+    {  // dO rows + delta = rowsum(dO o O); all loads first
+      const int part = tid & 3, r0 = tid >> 2;
+      u16x8 xd[NP][3], xo[NP][3];
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) {
+        const int row = r0 + 64 * ps;
         if (row < S) {
           const u16x8* p = (const u16x8*)(g.d_o + (seq * S + row) * E + h * DH + part * 24);
           const u16x8* po = (const u16x8*)(g.o + (seq * S + row) * E + h * DH + part * 24);
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            x[c] = p[c]; const u16x8 ov = po[c];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dsum += bf2f(x[c][j]) * bf2f(ov[j]);
-          }
+          for (int c = 0; c < 3; ++c) { xd[ps][c] = p[c]; xo[ps][c] = po[c]; }
         } else {
 #pragma unroll
           for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[c][j] = 0;
+            for (int j = 0; j < 8; ++j) { xd[ps][c][j] = 0; xo[ps][c][j] = 0; }
         }
+      }
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) {
+        const int row = r0 + 64 * ps;
+        float dsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dsum += bf2f(xd[ps][c][j]) * bf2f(xo[ps][c][j]);
         dsum += __shfl_xor(dsum, 1, 64); dsum += __shfl_xor(dsum, 2, 64);
-        u16x8* d = (u16x8*)(dOs + row * ROWB + part * 48);
-        d[0] = x[0]; d[1] = x[1]; d[2] = x[2];
-        if (part == 0) drow[row] = dsum;
+        if (row < S_pad) {
+          u16x8* d = (u16x8*)(dOs + row * ROWB + part * 48);
+          d[0] = xd[ps][0]; d[1] = xd[ps][1]; d[2] = xd[ps][2];
+          if (part == 0) drow[row] = dsum;
+        }
       }
     }
     for (int t = tid; t < S_pad; t += 256) {

@@ -94,6 +94,11 @@ struct spa3d_ctx {
   int hip_err = 0;
   int gemm_impl = 0;  // 0 auto, 1 generic only
   int attn_impl = 0;
+  int nt_astat = 0;   // A-stationary NT kernel for short-K / wide-N shapes: measured SLOWER at 1 wave/SIMD (452 vs 600 TF/s), off;
+                      // SPA3D_NT_ASTAT=1 enables, =2 forces (tests)
+  int nt_persist = 0; // persistent NT kernel with cross-tile prefetch: measured slower (in-order vmcnt ties the next tile's
+                      // loads to the epilogue stores), off; SPA3D_NT_PERSIST=1 enables
+  int nt_occ = 1;     // single-buffer 4-workgroups/CU NT kernel for K <= 512 (SPA3D_NT_OCC=0 disables)
   Prof prof;
 };
 

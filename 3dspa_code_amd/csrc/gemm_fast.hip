@@ -169,6 +169,409 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
   }
 }
 
+
+// =================================================================================================================
+// A-stationary NT GEMM for short K (K <= 512) and wide N: the shapes of the QKV / MLP-in projections and of the dX of
+// the out / MLP-out projections (K = 384), where a 128x128 tile re-stages its whole A panel for every one of the N/128
+// column tiles and the kernel is bound by LDS-DMA delivery (64 FLOP per staged byte), not by MFMA issue.
+// One workgroup owns a 128-row M tile: the [128 x K] A panel is staged ONCE (K/64 swizzled 16-KiB images, 96 KiB at
+// K = 384) and stays resident; the weight tiles [128 x 64] of all N tiles stream through a 4-slot LDS ring, three
+// tiles in flight behind a COUNTED `s_waitcnt vmcnt` and a raw `s_barrier` per K-step (cdna_hip_programming.md
+// "Pipelining across barriers"), so the stream never drains between column tiles: 128 FLOP per staged byte, one
+// prologue per M tile, A read from HBM exactly once, weights always from L2.
+// =================================================================================================================
+template <int KT>
+__global__ __launch_bounds__(256, 1) void gemm_nt_astat_kernel(NtArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [KT][A image 16 KiB] | [NB][B tile 16 KiB]
+  constexpr int NB = 4;
+  char* const sA = smem; char* const sB = smem + KT * 16384;
+  const int tm = blockIdx.x;
+  const int64_t m0 = (int64_t)tm * 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sr = lane >> 3, scp = lane & 7;
+  const int sc = (scp ^ sr) * 8;
+  const int nsteps = g.tiles_n * KT;
+
+  // per-lane source rows: wave w fills 8-row groups 4w..4w+3 of every staged tile
+  const bf16_t* ga[4]; int brow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (w * 4 + i) * 8 + sr;
+    int64_t am = m0 + row; if (am > g.M - 1) am = g.M - 1;
+    ga[i] = g.A + am * g.lda + sc;
+    brow[i] = row;
+  }
+  auto stage_b = [&](int step) {  // weight tile of K-step `step` -> ring slot step % NB
+    const int nt = step / KT, kt = step - nt * KT;
+    char* sb = sB + (step % NB) * 16384 + (w * 4) * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int bn = nt * 128 + brow[i]; if (bn > g.N - 1) bn = g.N - 1;
+      GLDS16(g.Bt + (int64_t)bn * g.ldb + sc + kt * 64, sb + i * 1024);
+    }
+  };
+  // ---- prologue: A panel, then the first NB-1 weight tiles
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    char* sa = sA + kt * 16384 + (w * 4) * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) GLDS16(ga[i] + kt * 64, sa + i * 1024);
+  }
+#pragma unroll
+  for (int p = 0; p < NB - 1; ++p) if (p < nsteps) stage_b(p);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int a_off = (wm + fr) * 128, b_off = (wn + fr) * 128;
+  const int x0 = ((fq) ^ (fr & 7)) * 16, x1 = ((4 + fq) ^ (fr & 7)) * 16;
+
+  // vmcnt counts loads, LDS-DMA and STORES in issue order.  When the epilogue is pure stores (no bias / residual /
+  // accumulate loads) and the tile is interior, exactly 16 (32 with a pre-activation copy) store instructions per wave sit
+  // between the weight tiles of two column tiles; counting them lets the stream run on while they drain.
+  const bool pure = !g.bias && !g.aux && !g.accumulate && (m0 + 128 <= g.M) && (g.N % 128 == 0);
+  const int nstore = g.pre_out ? 32 : 16;
+  int kt = 0, nt = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    // tile `step` (and the A panel before it) has landed once at most the 2 younger tiles (4 LDS-DMA each) -- plus, for the
+    // three steps after an epilogue, its stores -- are outstanding; at the tail fewer tiles are in flight: wait for all.
+    if (step + 2 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (pure && nt > 0 && kt < 3) { if (nstore == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // slot (step+3) % 4 == (step-1) % 4 was last read in step-1, which every wave has left: safe to refill now
+    if (step + NB - 1 < nsteps) stage_b(step + NB - 1);
+    const char* sa = sA + kt * 16384;
+    const char* sb = sB + (step % NB) * 16384;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int xo = ks ? x1 : x0;
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + a_off + i * 2048 + xo);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + b_off + j * 2048 + xo);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (++kt == KT) {
+      // ---- epilogue of column tile nt, straight from registers: lane holds C[m = wm+16i+fr][n = wn+16j+4fq .. +3]
+      const int n0 = nt * 128;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t gm = m0 + wm + i * 16 + fr;
+        int64_t crow = gm;
+        if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int gn = n0 + wn + j * 16 + fq * 4;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] = g.alpha * acc[i][j][r]; acc[i][j][r] = 0.f; }
+          if (gm >= g.M || gn >= g.N) continue;
+          if (g.bias) { const float4 b4 = *(const float4*)(g.bias + gn); v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
+          const int64_t ci = crow * g.ldc + gn;
+          if (g.pre_out) { u16x4 p4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p4[r] = f2bf(v[r]);
+            *(u16x4*)(g.pre_out + ci) = p4; }
+          if (g.epi == EPI_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+          }
+          if (g.aux) {
+            const u16x4 x4 = *(const u16x4*)(g.aux + ci);
+            if (g.epi == EPI_MUL_GELU_GRAD) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bf2f(x4[r]);
+            }
+          }
+          if (g.out_f32) {
+            float4* cp = (float4*)((float*)g.C + ci);
+            if (g.accumulate) { const float4 o = *cp; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+            *cp = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            u16x4* cp = (u16x4*)((bf16_t*)g.C + ci);
+            if (g.accumulate) { const u16x4 o = *cp;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bf2f(o[r]); }
+            u16x4 o4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o4[r] = f2bf(v[r]);
+            *cp = o4;
+          }
+        }
+      }
+      kt = 0; ++nt;
+    }
+  }
+}
+
+template <int KT>
+static void launch_astat(spa3d_ctx* c, const NtArgs& g) {
+  const int lds = (KT + 4) * 16384;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_astat_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  gemm_nt_astat_kernel<KT><<<(unsigned)g.tiles_m, 256, lds, c->stream>>>(g);
+}
+
+
+// =================================================================================================================
+// Persistent variant of gemm_nt_kernel.  Fitting T(K) of the one-tile-per-workgroup kernel on the step's shapes gives
+// ~1.0 us per K-tile but ~5 us of FIXED cost per 128x128 output tile (workgroup launch, first-tile DMA latency, store
+// tail) -- as much as the whole K loop at K = 384.  Here 2 workgroups per CU stay resident and walk the tile list;
+// the first K-tile of the NEXT output tile is staged into the free LDS buffer under the last K-tile of the current
+// one, and the epilogue goes straight from registers (no LDS, no barrier) so it overlaps that DMA.
+// =================================================================================================================
+__global__ __launch_bounds__(256, 2) void gemm_nt_persist_kernel(NtArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 16 KiB | B 16 KiB]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sr = lane >> 3, scp = lane & 7;
+  const int sc = (scp ^ sr) * 8;
+  const int nvirt = ((g.tiles_m + 7) / 8) * 8 * g.tiles_n;  // virtual ids; gridDim.x % 8 == 0 keeps a workgroup on "its" XCD lane
+  const int nt = g.K / 64;
+  const int a_off = (wm + fr) * 128, b_off = (wn + fr) * 128;
+  const int x0 = ((fq) ^ (fr & 7)) * 16, x1 = ((4 + fq) ^ (fr & 7)) * 16;
+
+  auto decode = [&](int v, int& tm, int& tn) { const int xcd = v & 7, idx = v >> 3; tm = (idx / g.tiles_n) * 8 + xcd; tn = idx % g.tiles_n; };
+  auto next_valid = [&](int v) { int tm, tn; for (; v < nvirt; v += gridDim.x) { decode(v, tm, tn); if (tm < g.tiles_m) return v; } return nvirt; };
+  const bf16_t* ga[4]; const bf16_t* gb[4];
+  auto setup = [&](int v, const bf16_t* (&pa)[4], const bf16_t* (&pb)[4]) {
+    int tm, tn; decode(v, tm, tn);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (w * 4 + i) * 8 + sr;
+      int64_t am = (int64_t)tm * 128 + row; if (am > g.M - 1) am = g.M - 1;
+      int bn = tn * 128 + row; if (bn > g.N - 1) bn = g.N - 1;
+      pa[i] = g.A + am * g.lda + sc; pb[i] = g.Bt + (int64_t)bn * g.ldb + sc;
+    }
+  };
+  auto stage = [&](int buf, int kt, const bf16_t* const (&pa)[4], const bf16_t* const (&pb)[4]) {
+    char* sa = smem + buf * 32768 + (w * 4) * 1024;
+    char* sb = sa + 16384;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) GLDS16(pa[i] + kt * 64, sa + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) GLDS16(pb[i] + kt * 64, sb + i * 1024);
+  };
+
+  int v = next_valid(blockIdx.x);
+  if (v >= nvirt) return;
+  setup(v, ga, gb);
+  stage(0, 0, ga, gb);
+  __syncthreads();
+  int cur = 0;
+  while (true) {
+    int tm, tn; decode(v, tm, tn);
+    const int vn = next_valid(v + gridDim.x);
+    const bool has_next = vn < nvirt;
+    const bf16_t* gan[4]; const bf16_t* gbn[4];
+    if (has_next) setup(vn, gan, gbn);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt) stage(cur ^ 1, t + 1, ga, gb);
+      else if (has_next) stage(cur ^ 1, 0, gan, gbn);  // next output tile's first K-tile, under this tile's last MFMAs + epilogue
+      const char* sa = smem + cur * 32768;
+      const char* sb = sa + 16384;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int xo = ks ? x1 : x0;
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + a_off + i * 2048 + xo);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + b_off + j * 2048 + xo);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+      if (t + 1 < nt) { __syncthreads(); cur ^= 1; }
+    }
+    // ---- epilogue straight from registers: lane holds C[m = wm+16i+fr][n = wn+16j+4fq .. +3]
+    const int64_t m0 = (int64_t)tm * 128; const int n0 = tn * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t gm = m0 + wm + i * 16 + fr;
+      int64_t crow = gm;
+      if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int gn = n0 + wn + j * 16 + fq * 4;
+        if (gm >= g.M || gn >= g.N) continue;
+        float vv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vv[r] = g.alpha * acc[i][j][r];
+        if (g.bias) { const float4 b4 = *(const float4*)(g.bias + gn); vv[0] += b4.x; vv[1] += b4.y; vv[2] += b4.z; vv[3] += b4.w; }
+        const int64_t ci = crow * g.ldc + gn;
+        if (g.pre_out) { u16x4 p4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p4[r] = f2bf(vv[r]);
+          *(u16x4*)(g.pre_out + ci) = p4; }
+        if (g.epi == EPI_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vv[r] = gelu_tanh_f(vv[r]);
+        }
+        if (g.aux) {
+          const u16x4 x4 = *(const u16x4*)(g.aux + ci);
+          if (g.epi == EPI_MUL_GELU_GRAD) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vv[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vv[r] += bf2f(x4[r]);
+          }
+        }
+        if (g.out_f32) {
+          float4* cp = (float4*)((float*)g.C + ci);
+          if (g.accumulate) { const float4 o = *cp; vv[0] += o.x; vv[1] += o.y; vv[2] += o.z; vv[3] += o.w; }
+          *cp = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {
+          u16x4* cp = (u16x4*)((bf16_t*)g.C + ci);
+          if (g.accumulate) { const u16x4 o = *cp;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vv[r] += bf2f(o[r]); }
+          u16x4 o4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o4[r] = f2bf(vv[r]);
+          *cp = o4;
+        }
+      }
+    }
+    if (!has_next) break;
+    __syncthreads();  // next tile's first K-tile has landed (vmcnt(0)) and every wave is done reading `cur`
+    cur ^= 1;
+    v = vn;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ga[i] = gan[i]; gb[i] = gbn[i]; }
+  }
+}
+
+
+// =================================================================================================================
+// High-occupancy variant for short K: ONE 32-KiB LDS buffer, direct register epilogue, 4 workgroups per CU.  No
+// intra-workgroup overlap (stage -> barrier -> MFMA -> barrier), instead four workgroups per CU interleave: one
+// block's first-tile latency and store tail hide under the others' K loops.
+// =================================================================================================================
+__global__ __launch_bounds__(256, 4) void gemm_nt_occ_kernel(NtArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [A 16 KiB | B 16 KiB]
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int tm = (idx / g.tiles_n) * 8 + xcd, tn = idx % g.tiles_n;
+  if (tm >= g.tiles_m) return;
+  const int64_t m0 = (int64_t)tm * 128;
+  const int n0 = tn * 128;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sr = lane >> 3, scp = lane & 7;
+  const int sc = (scp ^ sr) * 8;
+  const bf16_t* ga[4]; const bf16_t* gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row = (w * 4 + i) * 8 + sr;
+    int64_t am = m0 + row; if (am > g.M - 1) am = g.M - 1;
+    int bn = n0 + row; if (bn > g.N - 1) bn = g.N - 1;
+    ga[i] = g.A + am * g.lda + sc;
+    gb[i] = g.Bt + (int64_t)bn * g.ldb + sc;
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nt = g.K / 64;
+  const int a_off = (wm + fr) * 128, b_off = (wn + fr) * 128;
+  const int x0 = ((fq) ^ (fr & 7)) * 16, x1 = ((4 + fq) ^ (fr & 7)) * 16;
+  char* const sa0 = smem + (w * 4) * 1024; char* const sb0 = sa0 + 16384;
+  for (int t = 0; t < nt; ++t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) GLDS16(ga[i] + t * 64, sa0 + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) GLDS16(gb[i] + t * 64, sb0 + i * 1024);
+    __syncthreads();
+    const char* sa = smem; const char* sb = smem + 16384;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int xo = ks ? x1 : x0;
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + a_off + i * 2048 + xo);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + b_off + j * 2048 + xo);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nt) __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t gm = m0 + wm + i * 16 + fr;
+    int64_t crow = gm;
+    if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gn = n0 + wn + j * 16 + fq * 4;
+      if (gm >= g.M || gn >= g.N) continue;
+      float vv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vv[r] = g.alpha * acc[i][j][r];
+      if (g.bias) { const float4 b4 = *(const float4*)(g.bias + gn); vv[0] += b4.x; vv[1] += b4.y; vv[2] += b4.z; vv[3] += b4.w; }
+      const int64_t ci = crow * g.ldc + gn;
+      if (g.pre_out) { u16x4 p4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p4[r] = f2bf(vv[r]);
+        *(u16x4*)(g.pre_out + ci) = p4; }
+      if (g.epi == EPI_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vv[r] = gelu_tanh_f(vv[r]);
+      }
+      if (g.aux) {
+        const u16x4 x4 = *(const u16x4*)(g.aux + ci);
+        if (g.epi == EPI_MUL_GELU_GRAD) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vv[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vv[r] += bf2f(x4[r]);
+        }
+      }
+      if (g.out_f32) {
+        float4* cp = (float4*)((float*)g.C + ci);
+        if (g.accumulate) { const float4 o = *cp; vv[0] += o.x; vv[1] += o.y; vv[2] += o.z; vv[3] += o.w; }
+        *cp = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      } else {
+        u16x4* cp = (u16x4*)((bf16_t*)g.C + ci);
+        if (g.accumulate) { const u16x4 o = *cp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vv[r] += bf2f(o[r]); }
+        u16x4 o4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[r] = f2bf(vv[r]);
+        *cp = o4;
+      }
+    }
+  }
+}
+
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
@@ -195,6 +598,30 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
   ProfScope ps(c, PROF_GEMM_NT, 2.0 * (double)d.M * d.N * d.K, ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * 2.0);
+  const int KT = d.K / 64;
+  if (c->nt_astat && KT >= 2 && KT <= 6 && g.tiles_n >= 3 && (g.tiles_m >= 512 || c->nt_astat == 2)) {  // short K, wide N: keep the A panel resident
+    switch (KT) {
+      case 2: launch_astat<2>(c, g); break;
+      case 3: launch_astat<3>(c, g); break;
+      case 4: launch_astat<4>(c, g); break;
+      case 5: launch_astat<5>(c, g); break;
+      default: launch_astat<6>(c, g); break;
+    }
+    SPA_LAUNCH_CHECK(c);
+    return true;
+  }
+  if (c->nt_occ && KT <= 8) {  // short K: single LDS buffer, 4 workgroups/CU (+12 % at K = 384: 594 -> 667 TF/s)
+    gemm_nt_occ_kernel<<<(unsigned)blocks, 256, 32768, c->stream>>>(g);
+    SPA_LAUNCH_CHECK(c);
+    return true;
+  }
+  if (c->nt_persist && blocks >= 2048) {  // experiment, off by default: measured 538 vs 594 TF/s at K = 384  // enough tiles for two resident workgroups per CU to amortise their prologue
+    static bool attr2 = false;
+    if (!attr2) { (void)hipFuncSetAttribute((const void*)gemm_nt_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr2 = true; }
+    gemm_nt_persist_kernel<<<512, 256, 65536, c->stream>>>(g);
+    SPA_LAUNCH_CHECK(c);
+    return true;
+  }
   gemm_nt_kernel<<<(unsigned)blocks, 256, 65536, c->stream>>>(g);
   SPA_LAUNCH_CHECK(c);
   return true;

@@ -989,13 +989,48 @@ INST(bf16_t)
 // ---------------------------------------------------------------------------------------------
 #define Q1_MAXIT 20   // S <= 320
 #define Q1_MAXC 32    // Dh/4 <= 32
+// contiguous C-channel part of a row -> f[0..C): 16-byte loads when C and the address allow, else element-wise
+template <typename T>
+__device__ __forceinline__ void q1_load(const T* p, int C, bool vec, float (&f)[Q1_MAXC]) {
+  constexpr int NV = VecOf<T>::N;
+  if (vec) {
+#pragma unroll
+    for (int i = 0; i < Q1_MAXC / NV; ++i)
+      if (i * NV < C) {
+        float t[NV]; load_vec<T, NV>(p + i * NV, t);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) f[i * NV + j] = t[j];
+      }
+  } else {
+#pragma unroll
+    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) f[j] = ld(p + j);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void q1_store(T* p, int C, bool vec, const float (&f)[Q1_MAXC]) {
+  constexpr int NV = VecOf<T>::N;
+  if (vec) {
+#pragma unroll
+    for (int i = 0; i < Q1_MAXC / NV; ++i)
+      if (i * NV < C) {
+        float t[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) t[j] = f[i * NV + j];
+        store_vec<T, NV>(p + i * NV, t);
+      }
+  } else {
+#pragma unroll
+    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) st(p + j, f[j]);
+  }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void attn_q1_fwd_kernel(const T* __restrict__ q0, int64_t ldq0, const T* __restrict__ k, const T* __restrict__ v,
                                                           int64_t ldk, int64_t ldv, const float* __restrict__ sq, const float* __restrict__ sk,
                                                           const float* __restrict__ km, int64_t nprob, int S, int H, int Dh,
-                                                          T* __restrict__ o0, float* __restrict__ p0) {
+                                                          T* __restrict__ o0, float* __restrict__ p0, int vec_) {
   const int lane = threadIdx.x & 63, part = lane & 3, kg = lane >> 2;
   const int C = Dh / 4, c0 = part * C;
+  const bool vec = vec_ != 0;
   const float alpha = rsqrtf((float)Dh);
   const int nit = (S + 15) / 16;
   for (int64_t prob = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); prob < nprob; prob += (int64_t)gridDim.x * 4) {
@@ -1016,8 +1051,9 @@ __global__ __launch_bounds__(256) void attn_q1_fwd_kernel(const T* __restrict__ 
         if (key < S) {
           const T* kr = k + (seq * S + key) * ldk + h * Dh + c0;
           float kv_[Q1_MAXC]; float ks = 0.f;
+          q1_load<T>(kr, C, vec, kv_);
 #pragma unroll
-          for (int j = 0; j < Q1_MAXC; ++j) if (j < C) { kv_[j] = ld(kr + j); ks += kv_[j] * kv_[j]; }
+          for (int j = 0; j < Q1_MAXC; ++j) if (j < C) ks += kv_[j] * kv_[j];
           ks += __shfl_xor(ks, 1, 64); ks += __shfl_xor(ks, 2, 64);
           const float rk = rsqrtf(ks / Dh + 1e-6f);
           float d = 0.f;
@@ -1051,8 +1087,10 @@ __global__ __launch_bounds__(256) void attn_q1_fwd_kernel(const T* __restrict__ 
           const float p = sc[it] * inv;
           if (part == 0) p0[prob * S + key] = p;
           const T* vr = v + (seq * S + key) * ldv + h * Dh + c0;
+          float vv[Q1_MAXC];
+          q1_load<T>(vr, C, vec, vv);
 #pragma unroll
-          for (int j = 0; j < Q1_MAXC; ++j) if (j < C) acc[j] += p * ld(vr + j);
+          for (int j = 0; j < Q1_MAXC; ++j) if (j < C) acc[j] += p * vv[j];
         }
       }
 #pragma unroll
@@ -1073,7 +1111,9 @@ void k_attn_q1_fwd(spa3d_ctx* c, const T* q0, int64_t ldq0, const T* k, const T*
   if (c->dry || nseq == 0) return;
   const int64_t nprob = nseq * H;
   unsigned g = (unsigned)std::min<int64_t>(cdiv(nprob, 4), 8192);
-  attn_q1_fwd_kernel<T><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, Dh, o0, p0);
+  constexpr int NV = VecOf<T>::N;
+  const int vec = ((Dh / 4) % NV == 0 && ldk % NV == 0 && ldv % NV == 0 && ((((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0) ? 1 : 0;
+  attn_q1_fwd_kernel<T><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, Dh, o0, p0, vec);
   SPA_LAUNCH_CHECK(c);
 }
 
@@ -1083,10 +1123,12 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
                                                           int64_t ldk, int64_t ldv, const float* __restrict__ sq, const float* __restrict__ sk,
                                                           const float* __restrict__ km, int64_t nprob, int S, int H, int Dh,
                                                           const float* __restrict__ p0, const T* __restrict__ d_o0, T* __restrict__ dq0,
-                                                          T* __restrict__ dk, T* __restrict__ dv, float* __restrict__ dsq, float* __restrict__ dsk) {
+                                                          T* __restrict__ dk, T* __restrict__ dv, float* __restrict__ dsq, float* __restrict__ dsk,
+                                                          int vec_) {
   __shared__ float red[2][4 * Q1_MAXC];
   const int lane = threadIdx.x & 63, part = lane & 3, kg = lane >> 2;
   const int C = Dh / 4, c0 = part * C;
+  const bool vec = vec_ != 0;
   const float alpha = rsqrtf((float)Dh);
   const int nit = (S + 15) / 16;
   float dsq_acc[Q1_MAXC], dsk_acc[Q1_MAXC];
@@ -1112,8 +1154,10 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
         float d = 0.f;
         if (key < S) {
           const T* vr = v + (seq * S + key) * ldv + h * Dh + c0;
+          float vv[Q1_MAXC];
+          q1_load<T>(vr, C, vec, vv);
 #pragma unroll
-          for (int j = 0; j < Q1_MAXC; ++j) if (j < C) d += dout[j] * ld(vr + j);
+          for (int j = 0; j < Q1_MAXC; ++j) if (j < C) d += dout[j] * vv[j];
         }
         d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64);
         dp[it] = d;
@@ -1134,8 +1178,9 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
         float xk[Q1_MAXC]; float ks = 0.f, p = 0.f; bool keep = true;
         const int64_t roff = valid ? (seq * S + key) : (seq * S);
         if (valid) { p = p0[prob * S + key]; keep = !(km && km[seq * S + key] == 0.f); }
+        q1_load<T>(k + roff * ldk + h * Dh + c0, C, vec, xk);
 #pragma unroll
-        for (int j = 0; j < Q1_MAXC; ++j) if (j < C) { xk[j] = ld(k + roff * ldk + h * Dh + c0 + j); ks += xk[j] * xk[j]; }
+        for (int j = 0; j < Q1_MAXC; ++j) if (j < C) ks += xk[j] * xk[j];
         ks += __shfl_xor(ks, 1, 64); ks += __shfl_xor(ks, 2, 64);
         const float rk = rsqrtf(ks / Dh + 1e-6f);
         const float ds = keep ? p * (dp[it] - pd) * alpha : 0.f;  // where() passes no gradient to masked logits
@@ -1150,14 +1195,17 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
         gx += __shfl_xor(gx, 1, 64); gx += __shfl_xor(gx, 2, 64);
         gx /= Dh;
         if (valid) {
+          float ok[Q1_MAXC], ov[Q1_MAXC];
 #pragma unroll
           for (int j = 0; j < Q1_MAXC; ++j)
             if (j < C) {
               const float dkh = ds * qh[j];
-              st(dk + roff * ldk + h * Dh + c0 + j, rk * (dkh * sk[c0 + j] - xk[j] * gx));
-              st(dv + roff * ldv + h * Dh + c0 + j, p * dout[j]);
+              ok[j] = rk * (dkh * sk[c0 + j] - xk[j] * gx);
+              ov[j] = p * dout[j];
               dsk_acc[j] += dkh * xk[j];
             }
+          q1_store<T>(dk + roff * ldk + h * Dh + c0, C, vec, ok);
+          q1_store<T>(dv + roff * ldv + h * Dh + c0, C, vec, ov);
         }
       }
     float gq = 0.f;
@@ -1204,7 +1252,10 @@ void k_attn_q1_bwd(spa3d_ctx* c, const T* q0, int64_t ldq0, const T* k, const T*
   if (c->dry || nseq == 0) return;
   const int64_t nprob = nseq * H;
   unsigned g = (unsigned)std::min<int64_t>(cdiv(nprob, 4), 2048);
-  attn_q1_bwd_kernel<T><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, Dh, p0, d_o0, dq0, dk, dv, dsq, dsk);
+  constexpr int NV = VecOf<T>::N;
+  const int vec = ((Dh / 4) % NV == 0 && ldk % NV == 0 && ldv % NV == 0 &&
+                   ((((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)dk) | ((uintptr_t)dv)) & 15) == 0) ? 1 : 0;
+  attn_q1_bwd_kernel<T><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, Dh, p0, d_o0, dq0, dk, dv, dsq, dsk, vec);
   SPA_LAUNCH_CHECK(c);
 }
 // dst[i*stride_rows][:] += src[i][:]

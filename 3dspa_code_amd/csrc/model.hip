@@ -688,6 +688,9 @@ int spa3d_create(const spa3d_config* cfg, spa3d_handle* out) {
   build_leaves(c);
   const char* e = getenv("SPA3D_GEMM_IMPL"); if (e) c->gemm_impl = atoi(e);
   e = getenv("SPA3D_ATTN_IMPL"); if (e) c->attn_impl = atoi(e);
+  e = getenv("SPA3D_NT_ASTAT"); if (e) c->nt_astat = atoi(e);
+  e = getenv("SPA3D_NT_PERSIST"); if (e) c->nt_persist = atoi(e);
+  e = getenv("SPA3D_NT_OCC"); if (e) c->nt_occ = atoi(e);
   *out = c;
   return SPA3D_OK;
 }

@@ -340,3 +340,26 @@ def test_attention_fused_fwd_bwd(lib, nseq, S, H, masked):
           rel_err(dsq, sqr.grad), rel_err(dsk, skr.grad)]
   print('fused attention bwd rel errs dq dk dv dsq dsk', errs)
   assert max(errs) < 3e-2
+
+
+@pytest.mark.parametrize('M,N,K,act,res,bias', [(4133, 2304, 384, 0, False, False), (1000, 1536, 384, 1, False, True),
+                                                (2050, 768, 256, 0, True, True), (700, 384, 128, 0, False, True)])
+def test_linear_tiled_nt_a_stationary(lib, monkeypatch, M, N, K, act, res, bias):
+  """the A-stationary variant (short K, wide N), forced on for small M with SPA3D_NT_ASTAT=2"""
+  monkeypatch.setenv('SPA3D_NT_ASTAT', '2')
+  test_linear_tiled_nt(lib, M, N, K, act, res, bias)
+
+
+@pytest.mark.parametrize('M,N,K,act,res,bias', [(40000, 1536, 384, 1, False, True), (70001, 384, 768, 0, True, True), (33000, 2304, 128, 0, False, False)])
+def test_linear_tiled_nt_persistent(lib, monkeypatch, M, N, K, act, res, bias):
+  """>= 2048 output tiles: the (experimental, default-off) persistent kernel with cross-tile prefetch"""
+  monkeypatch.setenv('SPA3D_NT_PERSIST', '1')
+  monkeypatch.setenv('SPA3D_NT_OCC', '0')
+  test_linear_tiled_nt(lib, M, N, K, act, res, bias)
+
+
+@pytest.mark.parametrize('M,N,K,act,res,bias', [(1000, 384, 256, 0, False, True), (4133, 2304, 384, 0, False, False), (2050, 384, 1536, 0, True, True)])
+def test_linear_tiled_nt_double_buffered(lib, monkeypatch, M, N, K, act, res, bias):
+  """the 2-buffer kernel with the LDS-staged epilogue also on the short-K shapes the single-buffer kernel normally takes"""
+  monkeypatch.setenv('SPA3D_NT_OCC', '0')
+  test_linear_tiled_nt(lib, M, N, K, act, res, bias)
