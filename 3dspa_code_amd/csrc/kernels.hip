@@ -990,24 +990,32 @@ INST(bf16_t)
 #define Q1_MAXIT 20   // S <= 320
 #define Q1_MAXC 32    // Dh/4 <= 32
 // contiguous C-channel part of a row -> f[0..C): 16-byte loads when C and the address allow, else element-wise
+// Channel map of a lane's Dh/4 values.  Vector path: 16-byte chunk i of the lane is chunk 4*i + part of the row, so the 4
+// lanes of a key read 64 contiguous bytes per instruction (3 instructions cover a 192-byte row).  Scalar path: contiguous.
 template <typename T>
-__device__ __forceinline__ void q1_load(const T* p, int C, bool vec, float (&f)[Q1_MAXC]) {
+__device__ __forceinline__ int q1_chan(int j, int part, int C, bool vec) {
+  constexpr int NV = VecOf<T>::N;
+  return vec ? (j / NV) * (4 * NV) + part * NV + (j % NV) : part * C + j;
+}
+// `p` points at channel 0 of the row (head offset applied); f[j] <-> channel q1_chan(j)
+template <typename T>
+__device__ __forceinline__ void q1_load(const T* p, int C, bool vec, float (&f)[Q1_MAXC], int part) {
   constexpr int NV = VecOf<T>::N;
   if (vec) {
 #pragma unroll
     for (int i = 0; i < Q1_MAXC / NV; ++i)
       if (i * NV < C) {
-        float t[NV]; load_vec<T, NV>(p + i * NV, t);
+        float t[NV]; load_vec<T, NV>(p + (4 * i + part) * NV, t);
 #pragma unroll
         for (int j = 0; j < NV; ++j) f[i * NV + j] = t[j];
       }
   } else {
 #pragma unroll
-    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) f[j] = ld(p + j);
+    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) f[j] = ld(p + part * C + j);
   }
 }
 template <typename T>
-__device__ __forceinline__ void q1_store(T* p, int C, bool vec, const float (&f)[Q1_MAXC]) {
+__device__ __forceinline__ void q1_store(T* p, int C, bool vec, const float (&f)[Q1_MAXC], int part) {
   constexpr int NV = VecOf<T>::N;
   if (vec) {
 #pragma unroll
@@ -1016,11 +1024,11 @@ __device__ __forceinline__ void q1_store(T* p, int C, bool vec, const float (&f)
         float t[NV];
 #pragma unroll
         for (int j = 0; j < NV; ++j) t[j] = f[i * NV + j];
-        store_vec<T, NV>(p + i * NV, t);
+        store_vec<T, NV>(p + (4 * i + part) * NV, t);
       }
   } else {
 #pragma unroll
-    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) st(p + j, f[j]);
+    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) st(p + part * C + j, f[j]);
   }
 }
 template <typename T>
@@ -1029,19 +1037,23 @@ __global__ __launch_bounds__(256) void attn_q1_fwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ km, int64_t nprob, int S, int H, int Dh,
                                                           T* __restrict__ o0, float* __restrict__ p0, int vec_) {
   const int lane = threadIdx.x & 63, part = lane & 3, kg = lane >> 2;
-  const int C = Dh / 4, c0 = part * C;
+  const int C = Dh / 4;
   const bool vec = vec_ != 0;
+  float sqv[Q1_MAXC], skv[Q1_MAXC];
+#pragma unroll
+  for (int j = 0; j < Q1_MAXC; ++j) if (j < C) { const int ch = q1_chan<T>(j, part, C, vec); sqv[j] = sq[ch]; skv[j] = sk[ch]; }
   const float alpha = rsqrtf((float)Dh);
   const int nit = (S + 15) / 16;
   for (int64_t prob = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); prob < nprob; prob += (int64_t)gridDim.x * 4) {
     const int64_t seq = prob / H; const int h = (int)(prob - seq * H);
     float qh[Q1_MAXC]; float ss = 0.f;
+    q1_load<T>(q0 + seq * ldq0 + h * Dh, C, vec, qh, part);
 #pragma unroll
-    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) { qh[j] = ld(q0 + seq * ldq0 + h * Dh + c0 + j); ss += qh[j] * qh[j]; }
+    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) ss += qh[j] * qh[j];
     ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64);
     const float rq = rsqrtf(ss / Dh + 1e-6f);
 #pragma unroll
-    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) qh[j] *= rq * sq[c0 + j];
+    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) qh[j] *= rq * sqv[j];
     float sc[Q1_MAXIT]; float m = -3.4028234663852886e38f;
 #pragma unroll
     for (int it = 0; it < Q1_MAXIT; ++it) {
@@ -1049,16 +1061,16 @@ __global__ __launch_bounds__(256) void attn_q1_fwd_kernel(const T* __restrict__ 
       if (it < nit) {
         const int key = it * 16 + kg;
         if (key < S) {
-          const T* kr = k + (seq * S + key) * ldk + h * Dh + c0;
+          const T* kr = k + (seq * S + key) * ldk + h * Dh;
           float kv_[Q1_MAXC]; float ks = 0.f;
-          q1_load<T>(kr, C, vec, kv_);
+          q1_load<T>(kr, C, vec, kv_, part);
 #pragma unroll
           for (int j = 0; j < Q1_MAXC; ++j) if (j < C) ks += kv_[j] * kv_[j];
           ks += __shfl_xor(ks, 1, 64); ks += __shfl_xor(ks, 2, 64);
           const float rk = rsqrtf(ks / Dh + 1e-6f);
           float d = 0.f;
 #pragma unroll
-          for (int j = 0; j < Q1_MAXC; ++j) if (j < C) d += qh[j] * kv_[j] * rk * sk[c0 + j];
+          for (int j = 0; j < Q1_MAXC; ++j) if (j < C) d += qh[j] * kv_[j] * rk * skv[j];
           d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64);
           float lg = d * alpha;
           if (km && km[seq * S + key] == 0.f) lg = -3.4028234663852886e38f;
@@ -1086,9 +1098,9 @@ __global__ __launch_bounds__(256) void attn_q1_fwd_kernel(const T* __restrict__ 
         if (key < S) {
           const float p = sc[it] * inv;
           if (part == 0) p0[prob * S + key] = p;
-          const T* vr = v + (seq * S + key) * ldv + h * Dh + c0;
+          const T* vr = v + (seq * S + key) * ldv + h * Dh;
           float vv[Q1_MAXC];
-          q1_load<T>(vr, C, vec, vv);
+          q1_load<T>(vr, C, vec, vv, part);
 #pragma unroll
           for (int j = 0; j < Q1_MAXC; ++j) if (j < C) acc[j] += p * vv[j];
         }
@@ -1099,10 +1111,7 @@ __global__ __launch_bounds__(256) void attn_q1_fwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int o = 4; o < 64; o <<= 1) acc[j] += __shfl_xor(acc[j], o, 64);
       }
-    if (kg == 0) {
-#pragma unroll
-      for (int j = 0; j < Q1_MAXC; ++j) if (j < C) st(o0 + seq * (int64_t)H * Dh + h * Dh + c0 + j, acc[j]);
-    }
+    if (kg == 0) q1_store<T>(o0 + seq * (int64_t)H * Dh + h * Dh, C, vec, acc, part);
   }
 }
 template <typename T>
@@ -1112,7 +1121,8 @@ void k_attn_q1_fwd(spa3d_ctx* c, const T* q0, int64_t ldq0, const T* k, const T*
   const int64_t nprob = nseq * H;
   unsigned g = (unsigned)std::min<int64_t>(cdiv(nprob, 4), 8192);
   constexpr int NV = VecOf<T>::N;
-  const int vec = ((Dh / 4) % NV == 0 && ldk % NV == 0 && ldv % NV == 0 && ((((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0) ? 1 : 0;
+  const int vec = (Dh % (4 * NV) == 0 && ldk % NV == 0 && ldv % NV == 0 && ldq0 % NV == 0 &&
+                   ((((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)q0) | ((uintptr_t)o0)) & 15) == 0) ? 1 : 0;
   attn_q1_fwd_kernel<T><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, Dh, o0, p0, vec);
   SPA_LAUNCH_CHECK(c);
 }
@@ -1127,8 +1137,11 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
                                                           int vec_) {
   __shared__ float red[2][4 * Q1_MAXC];
   const int lane = threadIdx.x & 63, part = lane & 3, kg = lane >> 2;
-  const int C = Dh / 4, c0 = part * C;
+  const int C = Dh / 4;
   const bool vec = vec_ != 0;
+  float sqv[Q1_MAXC], skv[Q1_MAXC];
+#pragma unroll
+  for (int j = 0; j < Q1_MAXC; ++j) if (j < C) { const int ch = q1_chan<T>(j, part, C, vec); sqv[j] = sq[ch]; skv[j] = sk[ch]; }
   const float alpha = rsqrtf((float)Dh);
   const int nit = (S + 15) / 16;
   float dsq_acc[Q1_MAXC], dsk_acc[Q1_MAXC];
@@ -1137,13 +1150,14 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
   for (int64_t prob = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); prob < nprob; prob += (int64_t)gridDim.x * 4) {
     const int64_t seq = prob / H; const int h = (int)(prob - seq * H);
     float xq[Q1_MAXC], qh[Q1_MAXC], dout[Q1_MAXC]; float ss = 0.f;
+    q1_load<T>(q0 + seq * ldq0 + h * Dh, C, vec, xq, part);
+    q1_load<T>(d_o0 + seq * (int64_t)H * Dh + h * Dh, C, vec, dout, part);
 #pragma unroll
-    for (int j = 0; j < Q1_MAXC; ++j)
-      if (j < C) { xq[j] = ld(q0 + seq * ldq0 + h * Dh + c0 + j); ss += xq[j] * xq[j]; dout[j] = ld(d_o0 + seq * (int64_t)H * Dh + h * Dh + c0 + j); }
+    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) ss += xq[j] * xq[j];
     ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64);
     const float rq = rsqrtf(ss / Dh + 1e-6f);
 #pragma unroll
-    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) { xq[j] *= rq; qh[j] = xq[j] * sq[c0 + j]; }
+    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) { xq[j] *= rq; qh[j] = xq[j] * sqv[j]; }
     // pass 1: dp_k = dO . V_k ; sum_k p_k dp_k
     float dp[Q1_MAXIT]; float pd = 0.f;
 #pragma unroll
@@ -1153,9 +1167,9 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
         const int key = it * 16 + kg;
         float d = 0.f;
         if (key < S) {
-          const T* vr = v + (seq * S + key) * ldv + h * Dh + c0;
+          const T* vr = v + (seq * S + key) * ldv + h * Dh;
           float vv[Q1_MAXC];
-          q1_load<T>(vr, C, vec, vv);
+          q1_load<T>(vr, C, vec, vv, part);
 #pragma unroll
           for (int j = 0; j < Q1_MAXC; ++j) if (j < C) d += dout[j] * vv[j];
         }
@@ -1178,7 +1192,7 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
         float xk[Q1_MAXC]; float ks = 0.f, p = 0.f; bool keep = true;
         const int64_t roff = valid ? (seq * S + key) : (seq * S);
         if (valid) { p = p0[prob * S + key]; keep = !(km && km[seq * S + key] == 0.f); }
-        q1_load<T>(k + roff * ldk + h * Dh + c0, C, vec, xk);
+        q1_load<T>(k + roff * ldk + h * Dh, C, vec, xk, part);
 #pragma unroll
         for (int j = 0; j < Q1_MAXC; ++j) if (j < C) ks += xk[j] * xk[j];
         ks += __shfl_xor(ks, 1, 64); ks += __shfl_xor(ks, 2, 64);
@@ -1189,8 +1203,8 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
         for (int j = 0; j < Q1_MAXC; ++j)
           if (j < C) {
             xk[j] *= rk;                                  // x^ of the key row
-            dqh[j] += ds * xk[j] * sk[c0 + j];            // dq^ += ds * k^
-            gx += ds * qh[j] * sk[c0 + j] * xk[j];        // g = dk^ * s_k ; dk^ = ds * q^
+            dqh[j] += ds * xk[j] * skv[j];                // dq^ += ds * k^
+            gx += ds * qh[j] * skv[j] * xk[j];            // g = dk^ * s_k ; dk^ = ds * q^
           }
         gx += __shfl_xor(gx, 1, 64); gx += __shfl_xor(gx, 2, 64);
         gx /= Dh;
@@ -1200,12 +1214,12 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
           for (int j = 0; j < Q1_MAXC; ++j)
             if (j < C) {
               const float dkh = ds * qh[j];
-              ok[j] = rk * (dkh * sk[c0 + j] - xk[j] * gx);
+              ok[j] = rk * (dkh * skv[j] - xk[j] * gx);
               ov[j] = p * dout[j];
               dsk_acc[j] += dkh * xk[j];
             }
-          q1_store<T>(dk + roff * ldk + h * Dh + c0, C, vec, ok);
-          q1_store<T>(dv + roff * ldv + h * Dh + c0, C, vec, ov);
+          q1_store<T>(dk + roff * ldk + h * Dh, C, vec, ok, part);
+          q1_store<T>(dv + roff * ldv + h * Dh, C, vec, ov, part);
         }
       }
     float gq = 0.f;
@@ -1214,17 +1228,16 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
       if (j < C) {
 #pragma unroll
         for (int o = 4; o < 64; o <<= 1) dqh[j] += __shfl_xor(dqh[j], o, 64);
-        gq += dqh[j] * sq[c0 + j] * xq[j];
+        gq += dqh[j] * sqv[j] * xq[j];
       }
     gq += __shfl_xor(gq, 1, 64); gq += __shfl_xor(gq, 2, 64);
     gq /= Dh;
     if (kg == 0) {
+      float oq[Q1_MAXC];
 #pragma unroll
       for (int j = 0; j < Q1_MAXC; ++j)
-        if (j < C) {
-          st(dq0 + seq * (int64_t)H * Dh + h * Dh + c0 + j, rq * (dqh[j] * sq[c0 + j] - xq[j] * gq));
-          dsq_acc[j] += dqh[j] * xq[j];
-        }
+        if (j < C) { oq[j] = rq * (dqh[j] * sqv[j] - xq[j] * gq); dsq_acc[j] += dqh[j] * xq[j]; }
+      q1_store<T>(dq0 + seq * (int64_t)H * Dh + h * Dh, C, vec, oq, part);
     }
   }
   // flush: sum over the 16 key groups (dsk) / take group 0 (dsq), then over the 4 waves, one atomic per channel per block
@@ -1239,10 +1252,11 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
       if (kg == 0) { atomicAdd(&red[1][part * Q1_MAXC + j], a); atomicAdd(&red[0][part * Q1_MAXC + j], dsq_acc[j]); }
     }
   __syncthreads();
-  for (int t = threadIdx.x; t < Dh; t += 256) {
+  for (int t = threadIdx.x; t < 4 * C; t += 256) {
     const int pt = t / C, j = t - pt * C;
-    atomicAdd(dsq + t, red[0][pt * Q1_MAXC + j]);
-    atomicAdd(dsk + t, red[1][pt * Q1_MAXC + j]);
+    const int ch = q1_chan<T>(j, pt, C, vec);
+    atomicAdd(dsq + ch, red[0][pt * Q1_MAXC + j]);
+    atomicAdd(dsk + ch, red[1][pt * Q1_MAXC + j]);
   }
 }
 template <typename T>
@@ -1253,8 +1267,9 @@ void k_attn_q1_bwd(spa3d_ctx* c, const T* q0, int64_t ldq0, const T* k, const T*
   const int64_t nprob = nseq * H;
   unsigned g = (unsigned)std::min<int64_t>(cdiv(nprob, 4), 2048);
   constexpr int NV = VecOf<T>::N;
-  const int vec = ((Dh / 4) % NV == 0 && ldk % NV == 0 && ldv % NV == 0 &&
-                   ((((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)dk) | ((uintptr_t)dv)) & 15) == 0) ? 1 : 0;
+  const int vec = (Dh % (4 * NV) == 0 && ldk % NV == 0 && ldv % NV == 0 && ldq0 % NV == 0 &&
+                   ((((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)dk) | ((uintptr_t)dv) | ((uintptr_t)q0) | ((uintptr_t)d_o0) |
+                     ((uintptr_t)dq0)) & 15) == 0) ? 1 : 0;
   attn_q1_bwd_kernel<T><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, Dh, p0, d_o0, dq0, dk, dv, dsq, dsk, vec);
   SPA_LAUNCH_CHECK(c);
 }
