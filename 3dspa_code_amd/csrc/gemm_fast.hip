@@ -572,6 +572,124 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_occ_kernel(NtArgs g) {
   }
 }
 
+
+// =================================================================================================================
+// 256x256x64 tile, 8 waves (2 x 4, 128x64 per wave, 32 accumulator tiles = 128 VGPRs), two 64-KiB LDS buffers.
+// Why: with LDS-DMA staging the 128x128 kernels are bound by (bytes in flight per CU) / (DMA latency) x (FLOP per
+// staged byte): 64 KiB / ~1.5 us x 64 FLOP/B ~ 700 TF/s, which is what they measure.  This tile keeps the same 64 KiB
+// in flight but does 128 FLOP per staged byte, and its 64 MFMAs per wave per K-tile (x 2 waves per SIMD ~ 1 us) cover one
+// DMA latency.  Same swizzle, same swapped-operand MFMA, direct register epilogue (8-byte stores).
+// =================================================================================================================
+__global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NtArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A 32 KiB | B 32 KiB]
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int tm = (idx / g.tiles_n) * 8 + xcd, tn = idx % g.tiles_n;  // tiles_* count 256-wide tiles here
+  if (tm >= g.tiles_m) return;
+  const int64_t m0 = (int64_t)tm * 256;
+  const int n0 = tn * 256;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = (w >> 2) * 128, wn = (w & 3) * 64;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sr = lane >> 3, scp = lane & 7;
+  const int sc = (scp ^ sr) * 8;
+  const bf16_t* ga[4]; const bf16_t* gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (w * 4 + i) * 8 + sr;  // 8 waves x 4 groups x 8 rows = 256 rows
+    int64_t am = m0 + row; if (am > g.M - 1) am = g.M - 1;
+    int bn = n0 + row; if (bn > g.N - 1) bn = g.N - 1;
+    ga[i] = g.A + am * g.lda + sc;
+    gb[i] = g.Bt + (int64_t)bn * g.ldb + sc;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* sa = smem + buf * 65536 + (w * 4) * 1024;
+    char* sb = sa + 32768;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) GLDS16(ga[i] + kt * 64, sa + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) GLDS16(gb[i] + kt * 64, sb + i * 1024);
+  };
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nt = g.K / 64;
+  stage(0, 0);
+  __syncthreads();
+  const int a_off = (wm + fr) * 128, b_off = (wn + fr) * 128;
+  const int x0 = ((fq) ^ (fr & 7)) * 16, x1 = ((4 + fq) ^ (fr & 7)) * 16;
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) stage(cur ^ 1, t + 1);
+    const char* sa = smem + cur * 65536;
+    const char* sb = sa + 32768;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int xo = ks ? x1 : x0;
+      bf16x8 bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + b_off + j * 2048 + xo);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bf16x8 af = *(const bf16x8*)(sa + a_off + i * 2048 + xo);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af, acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t gm = m0 + wm + i * 16 + fr;
+    int64_t crow = gm;
+    if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gn = n0 + wn + j * 16 + fq * 4;
+      if (gm >= g.M || gn >= g.N) continue;
+      float vv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vv[r] = g.alpha * acc[i][j][r];
+      if (g.bias) { const float4 b4 = *(const float4*)(g.bias + gn); vv[0] += b4.x; vv[1] += b4.y; vv[2] += b4.z; vv[3] += b4.w; }
+      const int64_t ci = crow * g.ldc + gn;
+      if (g.pre_out) { u16x4 p4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p4[r] = f2bf(vv[r]);
+        *(u16x4*)(g.pre_out + ci) = p4; }
+      if (g.epi == EPI_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vv[r] = gelu_tanh_f(vv[r]);
+      }
+      if (g.aux) {
+        const u16x4 x4 = *(const u16x4*)(g.aux + ci);
+        if (g.epi == EPI_MUL_GELU_GRAD) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vv[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vv[r] += bf2f(x4[r]);
+        }
+      }
+      if (g.out_f32) {
+        float4* cp = (float4*)((float*)g.C + ci);
+        if (g.accumulate) { const float4 o = *cp; vv[0] += o.x; vv[1] += o.y; vv[2] += o.z; vv[3] += o.w; }
+        *cp = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      } else {
+        u16x4* cp = (u16x4*)((bf16_t*)g.C + ci);
+        if (g.accumulate) { const u16x4 o = *cp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vv[r] += bf2f(o[r]); }
+        u16x4 o4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[r] = f2bf(vv[r]);
+        *cp = o4;
+      }
+    }
+  }
+}
+
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
@@ -599,6 +717,17 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
   ProfScope ps(c, PROF_GEMM_NT, 2.0 * (double)d.M * d.N * d.K, ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * 2.0);
   const int KT = d.K / 64;
+  // 256x256 tile (128 FLOP per staged byte): measured +3..4 % over 128x128 at K >= 1280 (850 vs 821, 917 vs 882 TF/s), equal at
+  // K = 768, and much slower at K = 384 (433 vs 667: one workgroup per CU cannot hide a 6-step tile's prologue/epilogue)
+  if (c->nt_256 && d.N % 256 == 0 && ((d.M >= 256 * 64 && KT >= 16) || c->nt_256 == 2)) {
+    NtArgs g2 = g; g2.tiles_m = (int)((d.M + 255) / 256); g2.tiles_n = d.N / 256;
+    const int64_t b2 = (int64_t)((g2.tiles_m + 7) / 8) * 8 * g2.tiles_n;
+    static bool attr3 = false;
+    if (!attr3) { (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr3 = true; }
+    gemm_nt256_kernel<<<(unsigned)b2, 512, 131072, c->stream>>>(g2);
+    SPA_LAUNCH_CHECK(c);
+    return true;
+  }
   if (c->nt_astat && KT >= 2 && KT <= 6 && g.tiles_n >= 3 && (g.tiles_m >= 512 || c->nt_astat == 2)) {  // short K, wide N: keep the A panel resident
     switch (KT) {
       case 2: launch_astat<2>(c, g); break;

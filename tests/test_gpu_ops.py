@@ -363,3 +363,11 @@ def test_linear_tiled_nt_double_buffered(lib, monkeypatch, M, N, K, act, res, bi
   """the 2-buffer kernel with the LDS-staged epilogue also on the short-K shapes the single-buffer kernel normally takes"""
   monkeypatch.setenv('SPA3D_NT_OCC', '0')
   test_linear_tiled_nt(lib, M, N, K, act, res, bias)
+
+
+@pytest.mark.parametrize('M,N,K,act,res,bias', [(4133, 2304, 384, 0, False, False), (1000, 1536, 384, 1, False, True),
+                                                (2050, 768, 256, 0, True, True), (700, 1280, 1536, 0, False, True), (300, 256, 64, 0, False, False)])
+def test_linear_tiled_nt_256(lib, monkeypatch, M, N, K, act, res, bias):
+  """the 256x256 8-wave kernel (N % 256 == 0), forced on for small M with SPA3D_NT_256=2"""
+  monkeypatch.setenv('SPA3D_NT_256', '2')
+  test_linear_tiled_nt(lib, M, N, K, act, res, bias)
