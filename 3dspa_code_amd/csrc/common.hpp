@@ -98,6 +98,8 @@ struct spa3d_ctx {
                       // SPA3D_NT_ASTAT=1 enables, =2 forces (tests)
   int nt_persist = 0; // persistent NT kernel with cross-tile prefetch: measured slower (in-order vmcnt ties the next tile's
                       // loads to the epilogue stores), off; SPA3D_NT_PERSIST=1 enables
+  int nt_astat2 = 0;  // two-team A-stationary NT kernel for K <= 384, N >= 512: 638 TF/s vs 667 for the single-buffer kernel, off;
+                      // SPA3D_NT_ASTAT2=1 enables, =2 forces small M (tests)
   int nt_256 = 1;     // 256x256 8-wave NT kernel for N % 256 == 0 (SPA3D_NT_256=0 disables; =2 forces small M in tests)
   int nt_occ = 1;     // single-buffer 4-workgroups/CU NT kernel for K <= 512 (SPA3D_NT_OCC=0 disables)
   Prof prof;

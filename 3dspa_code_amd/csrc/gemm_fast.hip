@@ -690,6 +690,147 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NtArgs g) {
   }
 }
 
+
+// =================================================================================================================
+// A-stationary NT GEMM, two teams.  The per-CU LDS-DMA path, not MFMA issue, bounds the 128x128 kernels (64 FLOP per
+// staged byte); the first A-stationary attempt halved the staged bytes but ran one wave per SIMD and lost.  Here a
+// 512-thread workgroup owns a 128-row M tile whose [128 x K] A panel is staged once (K <= 384: 96 KiB) and two teams of
+// 4 waves walk the column tiles (team t takes tiles t, t+2, ..), each streaming its own weight tiles through a private
+// 2-slot ring: 128 FLOP per staged byte AND two waves per SIMD, so one team's MFMAs cover the other's DMA issue / LDS
+// reads.  One s_barrier per K-step for both teams; epilogue straight from registers.
+// =================================================================================================================
+template <int KT>
+__global__ __launch_bounds__(512, 2) void gemm_nt_astat2_kernel(NtArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [KT][A image 16 KiB] | team0 [2][16 KiB] | team1 [2][16 KiB]
+  char* const sA = smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = w >> 2, tw = w & 3;
+  char* const sB = smem + KT * 16384 + team * 32768;
+  const int64_t m0 = (int64_t)blockIdx.x * 128;
+  const int wm = (tw >> 1) * 64, wn = (tw & 1) * 64;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sr = lane >> 3, scp = lane & 7;
+  const int sc = (scp ^ sr) * 8;
+  const int my_tiles = (g.tiles_n - team + 1) / 2;           // column tiles of this team
+  const int max_tiles = (g.tiles_n + 1) / 2;                 // team 0's count: the loop length for both (barriers must match)
+  const int nsteps = max_tiles * KT, my_steps = my_tiles * KT;
+
+  // A panel: 16 pieces of 1 KiB per image, 2 per wave
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int grp = w * 2 + i;
+      int64_t am = m0 + grp * 8 + sr; if (am > g.M - 1) am = g.M - 1;
+      GLDS16(g.A + am * g.lda + sc + kt * 64, sA + kt * 16384 + grp * 1024);
+    }
+  auto stage_b = [&](int step) {  // this team's weight tile of its K-step `step` -> slot step & 1
+    const int ti = step / KT, kt = step - ti * KT;
+    const int nt = team + 2 * ti;
+    char* sb = sB + (step & 1) * 16384 + (tw * 4) * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int bn = nt * 128 + (tw * 4 + i) * 8 + sr; if (bn > g.N - 1) bn = g.N - 1;
+      GLDS16(g.Bt + (int64_t)bn * g.ldb + sc + kt * 64, sb + i * 1024);
+    }
+  };
+  if (my_steps > 0) stage_b(0);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int a_off = (wm + fr) * 128, b_off = (wn + fr) * 128;
+  const int x0 = ((fq) ^ (fr & 7)) * 16, x1 = ((4 + fq) ^ (fr & 7)) * 16;
+
+  int kt = 0, ti = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    __syncthreads();  // tile `step` (and, first time, the A panel) landed; every wave is done with the slot refilled next
+    if (step + 1 < my_steps) stage_b(step + 1);
+    if (step < my_steps) {
+      const char* sa = sA + kt * 16384;
+      const char* sb = sB + (step & 1) * 16384;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int xo = ks ? x1 : x0;
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + a_off + i * 2048 + xo);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + b_off + j * 2048 + xo);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (++kt == KT) {
+      if (step < my_steps) {
+        const int n0 = (team + 2 * ti) * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t gm = m0 + wm + i * 16 + fr;
+          int64_t crow = gm;
+          if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int gn = n0 + wn + j * 16 + fq * 4;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = g.alpha * acc[i][j][r]; acc[i][j][r] = 0.f; }
+            if (gm >= g.M || gn >= g.N) continue;
+            if (g.bias) { const float4 b4 = *(const float4*)(g.bias + gn); v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
+            const int64_t ci = crow * g.ldc + gn;
+            if (g.pre_out) { u16x4 p4;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) p4[r] = f2bf(v[r]);
+              *(u16x4*)(g.pre_out + ci) = p4; }
+            if (g.epi == EPI_GELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+            }
+            if (g.aux) {
+              const u16x4 x4 = *(const u16x4*)(g.aux + ci);
+              if (g.epi == EPI_MUL_GELU_GRAD) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bf2f(x4[r]);
+              }
+            }
+            if (g.out_f32) {
+              float4* cp = (float4*)((float*)g.C + ci);
+              if (g.accumulate) { const float4 o = *cp; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+              *cp = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+              u16x4* cp = (u16x4*)((bf16_t*)g.C + ci);
+              if (g.accumulate) { const u16x4 o = *cp;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bf2f(o[r]); }
+              u16x4 o4;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o4[r] = f2bf(v[r]);
+              *cp = o4;
+            }
+          }
+        }
+      }
+      kt = 0; ++ti;
+    }
+  }
+}
+
+template <int KT>
+static void launch_astat2(spa3d_ctx* c, const NtArgs& g) {
+  const int lds = KT * 16384 + 65536;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_astat2_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+  gemm_nt_astat2_kernel<KT><<<(unsigned)g.tiles_m, 512, lds, c->stream>>>(g);
+}
+
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
@@ -725,6 +866,17 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
     static bool attr3 = false;
     if (!attr3) { (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr3 = true; }
     gemm_nt256_kernel<<<(unsigned)b2, 512, 131072, c->stream>>>(g2);
+    SPA_LAUNCH_CHECK(c);
+    return true;
+  }
+  if (c->nt_astat2 && KT >= 2 && KT <= 6 && g.tiles_n >= 4 && (g.tiles_m >= 512 || c->nt_astat2 == 2)) {  // two-team A-stationary
+    switch (KT) {
+      case 2: launch_astat2<2>(c, g); break;
+      case 3: launch_astat2<3>(c, g); break;
+      case 4: launch_astat2<4>(c, g); break;
+      case 5: launch_astat2<5>(c, g); break;
+      default: launch_astat2<6>(c, g); break;
+    }
     SPA_LAUNCH_CHECK(c);
     return true;
   }

@@ -371,3 +371,12 @@ def test_linear_tiled_nt_256(lib, monkeypatch, M, N, K, act, res, bias):
   """the 256x256 8-wave kernel (N % 256 == 0), forced on for small M with SPA3D_NT_256=2"""
   monkeypatch.setenv('SPA3D_NT_256', '2')
   test_linear_tiled_nt(lib, M, N, K, act, res, bias)
+
+
+@pytest.mark.parametrize('M,N,K,act,res,bias', [(4133, 2304, 384, 0, False, False), (1000, 1536, 384, 1, False, True),
+                                                (2050, 768, 256, 0, True, True), (700, 640, 128, 0, False, True)])
+def test_linear_tiled_nt_a_stationary_two_teams(lib, monkeypatch, M, N, K, act, res, bias):
+  """two 4-wave teams sharing one resident A panel (odd and even column-tile counts), forced on for small M"""
+  monkeypatch.setenv('SPA3D_NT_ASTAT2', '2')
+  monkeypatch.setenv('SPA3D_NT_256', '0')
+  test_linear_tiled_nt(lib, M, N, K, act, res, bias)
