@@ -75,6 +75,9 @@ _SIGS = {
     'spa3d_op_attention_bwd': (C.c_int, [C.c_void_p] * 3 + [C.c_int64] * 3 + [C.c_void_p] * 3 + [C.c_int64]
                                + [C.c_int32] * 4 + [C.c_void_p] * 8 + [C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
                                                                        C.c_void_p]),
+    'spa3d_op_sample_dino': (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p, C.c_int32, C.c_void_p]),
+    'spa3d_op_sample_depth_features': (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p]),
+    'spa3d_op_lift_2d_to_3d': (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.POINTER(C.c_double), C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -182,6 +182,20 @@ int spa3d_op_attention_bwd(const void* q, const void* k, const void* v, int64_t 
                            const void* d_o, void* dq, void* dk, void* dv, float* dscale_q, float* dscale_k,
                            int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream);
 
+/* ---- feature producers that build the hot path's inputs.  Host pointers: `intrinsics` only. ----
+ * Float32 arithmetic in the reference's operation order: bit-identical to the reference functions under NumPy >= 2. */
+
+/* sample_dino_features_for_tracks (inference.py:339-395): feat [T,Hp,Wp,D] f32, tracks_2d [N,T,2] f32 in pixels of an
+ * H x W video -> out [N,T,D] (out_dtype SPA3D_F32 as the reference, or SPA3D_BF16 = the same values rounded once). */
+int spa3d_op_sample_dino(const float* feat, const float* tracks_2d, int32_t N, int32_t T, int32_t Hp, int32_t Wp, int32_t D,
+                         int32_t H, int32_t W, void* out, int32_t out_dtype, void* stream);
+/* sample_depth_features_for_tracks (inference.py:398-447): depth [T,H,W,1] f32 -> out [N,T,256] f32 */
+int spa3d_op_sample_depth_features(const float* depth, const float* tracks_2d, int32_t N, int32_t T, int32_t H, int32_t W,
+                                   float* out, void* stream);
+/* lift_2d_to_3d (inference.py:287-336): intrinsics = host double[4] {fx,fy,cx,cy} or NULL (fx=fy=max(H,W), cx=W/2, cy=H/2) */
+int spa3d_op_lift_2d_to_3d(const float* tracks_2d, const float* depth, int32_t N, int32_t T, int32_t H, int32_t W,
+                           const double* intrinsics, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
