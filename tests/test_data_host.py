@@ -1,0 +1,90 @@
+"""Host-side rows either side of the path: batch preparation, TAPVid-3D adapter, checkpoint I/O.
+CPU tests use device='cpu' tensors (these functions only move data); the resume test needs the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import MINI, O, product_model
+
+
+@pytest.fixture(scope='module')
+def spa3d():
+  import spa3d as s
+  return s
+
+
+def test_prepare_3d_batch_follows_the_reference_rng_sequence(spa3d):
+  rng = np.random.default_rng(0)
+  ex = {'tracks_3d': rng.random((40, 12, 3)).astype(np.float32), 'visible': (rng.random((40, 12, 1)) < 0.8).astype(np.float32),
+        'dino_features': rng.standard_normal((40, 12, 16)).astype(np.float32), 'depth_features': rng.random((40, 12, 2)).astype(np.float32)}
+  np.random.seed(7)
+  b = spa3d.prepare_3d_batch(ex, num_support_tracks=24, num_query_tracks=10, num_frames=12, device='cpu', feature_dtype=torch.float32)
+  # restate data_loader.py:66-85 literally with the same seed
+  np.random.seed(7)
+  idx = np.random.permutation(40)
+  sup, qry = idx[:24], idx[24:34]
+  qp = []
+  for i in range(10):
+    t = np.random.randint(0, 12)
+    qp.append([t, *ex['tracks_3d'][qry][i, t]])
+  assert np.array_equal(b['support_tracks'][0].numpy(), ex['tracks_3d'][sup])
+  assert np.array_equal(b['query_tracks_visible'][0].numpy(), ex['visible'][qry])
+  assert np.allclose(b['query_points'][0].numpy(), np.array(qp, dtype=np.float32))
+  assert np.array_equal(b['dino_features'][0].numpy(), ex['dino_features'][sup])
+  assert b['boundary_frame'].tolist() == [12] and b['support_tracks'].shape == (1, 24, 12, 3)
+  b2 = spa3d.prepare_3d_batch({k: ex[k] for k in ('tracks_3d', 'visible')}, 24, 10, 12, device='cpu')
+  assert 'dino_features' not in b2 and 'depth_features' not in b2
+  with pytest.raises(IndexError):
+    spa3d.prepare_3d_batch(ex, 36, 10, 12, device='cpu')
+
+
+def test_tapvid3d_adapter(spa3d):
+  tr = torch.arange(2 * 3 * 4 * 3, dtype=torch.float32).reshape(2, 3, 4, 3)
+  lg = torch.tensor([[-1.0, 0.0, 2.0, -0.5]] * 3)[None].repeat(2, 1, 1)[..., None]
+  p = spa3d.TrackAutoEncoderResults(tr, lg, torch.zeros_like(lg))
+  pt, occ = spa3d.convert_predictions_to_tapvid3d_format(p, None)
+  assert pt.shape == (4, 3, 3) and occ.shape == (4, 3)
+  assert np.array_equal(pt[1, 2], tr[0, 2, 1].numpy())
+  assert occ[:, 0].tolist() == [True, True, False, True]  # logit <= 0 means occluded (evaluate_tapvid3d.py:55)
+
+
+def test_checkpoint_flat_npz_round_trip(spa3d, tmp_path):
+  cfg = O.Config(**MINI, use_dino=True, use_depth=True, dino_feature_dim=6, depth_feature_dim=2)
+  p = O.init_params(cfg, seed=1, depth_dim=2)
+  path = spa3d.save_checkpoint(str(tmp_path / 'ck' / 'checkpoint_10'), p)
+  assert path.endswith('.npz')
+  q = spa3d.load_checkpoint(path)  # allow_pickle=False
+  fa, fb = O.tree_flatten(p), O.tree_flatten(q)
+  assert set(fa) == set(fb) and all(np.array_equal(fa[k].numpy(), fb[k]) for k in fa)
+  assert set(np.load(path).files) == set(fa)  # flat 'a/b/c' keys: the layout the reference's loader also accepts
+  # the model takes the loaded tree as is (plain nested dict of numpy arrays -> packed flat buffer)
+  model = product_model(spa3d, cfg, 'fp32')
+  flat = model.flat_from_tree({k: {kk: vv for kk, vv in v.items()} if isinstance(v, dict) else v for k, v in q.items()}, device='cpu')
+  assert flat.numel() == model._handle(6, 2)[2]
+  with pytest.raises(FileNotFoundError):
+    spa3d.load_checkpoint(str(tmp_path / 'missing.npz'))
+  # pickled layouts are refused unless the caller opts in
+  np.savez(str(tmp_path / 'pk.npz'), params=np.array({'a': 1}, dtype=object))
+  with pytest.raises(ValueError):
+    spa3d.load_checkpoint(str(tmp_path / 'pk.npz'))
+
+
+@pytest.mark.gpu
+def test_train_state_resume_is_exact(spa3d, tmp_path):
+  cfg = O.Config(**MINI, use_dino=False, use_depth=False)
+  batch = {k: v.cuda() for k, v in O.synthetic_batch(2, 6, 4, 8).items()}
+  noise = torch.rand(2, cfg.num_latent_tokens, cfg.latent_token_dim).cuda()
+  m1 = product_model(spa3d, cfg, 'fp32')
+  s1 = spa3d.TrainState(m1, m1.init(0, batch)['params'], learning_rate=1e-2, warmup_steps=2, total_steps=10)
+  for _ in range(2):
+    s1.train_step(batch, noise=noise)
+  path = spa3d.save_checkpoint(str(tmp_path / 'resume'), s1.params, s1)
+  m2 = product_model(spa3d, cfg, 'fp32')
+  s2 = spa3d.TrainState(m2, m2.init(123, batch)['params'], learning_rate=1e-2, warmup_steps=2, total_steps=10)
+  spa3d.load_train_state(path, s2)
+  assert s2.step == 2 and torch.equal(s2.flat, s1.flat) and torch.equal(s2.m, s1.m) and torch.equal(s2.v, s1.v)
+  a = s1.train_step(batch, noise=noise)
+  b = s2.train_step(batch, noise=noise)
+  assert torch.allclose(s1.flat, s2.flat, atol=1e-7) and abs(float(a['train/loss']) - float(b['train/loss'])) < 1e-3 * abs(float(a['train/loss']))
