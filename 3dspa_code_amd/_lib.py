@@ -19,7 +19,7 @@ class Config(C.Structure):
       ('dino_feature_dim', C.c_int32), ('depth_feature_dim', C.c_int32), ('num_heads', C.c_int32),
       ('qkv_size', C.c_int32), ('enc_mlp', C.c_int32), ('enc_layers', C.c_int32), ('t2l_mlp', C.c_int32),
       ('t2l_layers', C.c_int32), ('dec_mlp', C.c_int32), ('dec_layers', C.c_int32), ('ro_mlp', C.c_int32),
-      ('ro_layers', C.c_int32), ('precision', C.c_int32),
+      ('ro_layers', C.c_int32), ('precision', C.c_int32), ('model_kind', C.c_int32),
   ]
 
 

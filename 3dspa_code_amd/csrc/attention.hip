@@ -97,7 +97,7 @@ void attention_bwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq
       d.nb1 = (int)ns; d.nb2 = H; d.bA1 = bS1; d.bA2 = bS2; d.bB1 = (int64_t)Sq * E; d.bB2 = Dh; d.bC1 = (int64_t)Sk * ldv; d.bC2 = Dh;
       gemm_generic<T>(c, d);
     }
-    k_softmax_bwd<T>(c, s, dp, ns * H * Sq, Sk);  // dp := dS
+    k_softmax_bwd<T>(c, s, dp, ns * H * Sq, Sk, km ? km + s0 * Sk : nullptr, (int64_t)H * Sq);  // dp := dS
     {  // dQn = alpha dS Kn
       GemmDesc d{};
       d.A = dp; d.B = kn; d.C = dqn; d.M = Sq; d.N = Dh; d.K = Sk;

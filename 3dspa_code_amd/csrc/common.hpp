@@ -167,9 +167,10 @@ template <typename T> void k_rmsnorm_heads(spa3d_ctx*, const T* x, int64_t ldx, 
 template <typename T> void k_rmsnorm_heads_bwd(spa3d_ctx*, const T* x, int64_t ldx, const float* scale, const T* dy, int64_t lddy, T* dx,
                                                int64_t lddx, float* dscale, int64_t rows, int H, int Dh);
 template <typename T> void k_softmax(spa3d_ctx*, T* s, const float* keymask, int64_t nseq, int H, int Sq, int Sk);
-template <typename T> void k_softmax_bwd(spa3d_ctx*, const T* p, T* dp, int64_t rows, int Sk);
+template <typename T> void k_softmax_bwd(spa3d_ctx*, const T* p, T* dp, int64_t rows, int Sk, const float* keymask = nullptr,
+                                         int64_t rows_per_seq = 1);
 template <typename T> void k_sin_embed(spa3d_ctx*, const float* x, int64_t rows, int C, int nf, float prescale, T* out);
-template <typename T> void k_embed_tokens(spa3d_ctx*, const float* tracks, int64_t nrows, int T_, int nf, float prescale, T* sinbuf);
+template <typename T> void k_embed_tokens(spa3d_ctx*, const float* tracks, int64_t nrows, int T_, int nf, float prescale, T* sinbuf, int NC = 3);
 template <typename T> void k_colsum(spa3d_ctx*, const T* x, int64_t rows, int n, int64_t ld, float* out /*accumulated*/, int rgroup = 0,
                                     int rskip = 0);
 template <typename T> void k_gelu(spa3d_ctx*, const T* x, T* y, int64_t n);
@@ -189,16 +190,18 @@ template <typename T> void k_compact_tokens(spa3d_ctx*, const T* tok, T* dst, in
 template <typename T> void k_broadcast_rows(spa3d_ctx*, const float* src, int rows, int d, T* dst, int64_t B);
 template <typename T> void k_bcast_grad(spa3d_ctx*, const T* dsrc, int64_t per, int64_t B, int64_t bstride, float* dparam);
 void k_discretize(spa3d_ctx*, const float* lat, const float* noise, int discretize, float* out, float* clipmask, int64_t n);
-void k_query_embed1(spa3d_ctx*, const float* qp, int64_t nq, int nf, float track_scale, float time_scale, float* feat, int32_t* qframe);
+void k_query_embed1(spa3d_ctx*, const float* qp, int64_t nq, int nf, float track_scale, float time_scale, float* feat, int32_t* qframe,
+                    int NC = 3);
 template <typename T> void k_assemble_readout(spa3d_ctx*, const T* qtok, const T* lat, const int32_t* qframe, int64_t B, int Q, int L, int Cl,
                                               int D, T* seq);
 template <typename T> void k_assemble_readout_bwd(spa3d_ctx*, const T* dseq, const int32_t* qframe, int64_t B, int Q, int L, int Cl, int D,
                                                   T* dqtok, float* dlat);
 void k_loss_fwd(spa3d_ctx*, const float* head, int64_t nq, int T_, const float* tgt, const float* tvis, float* tracks, float* vlog,
-                float* clog, float* sums);
-void k_loss_from_preds(spa3d_ctx*, const float* tracks, const float* vlog, int64_t n, const float* tgt, const float* tvis, float* sums);
+                float* clog, float* sums, int NC = 3);
+void k_loss_from_preds(spa3d_ctx*, const float* tracks, const float* vlog, int64_t n, const float* tgt, const float* tvis, float* sums,
+                       int NC = 3);
 template <typename T> void k_loss_bwd(spa3d_ctx*, const float* head, int64_t nq, int T_, const float* tgt, const float* tvis,
-                                      const float* denom_dev, float l1w, float bcew, T* dhead);
+                                      const float* denom_dev, float l1w, float bcew, T* dhead, int NC = 3);
 void k_vis_count(spa3d_ctx*, const float* tvis, int64_t n, float* out);
 void k_set_denom(spa3d_ctx*, const float* sums, float denom_host, float* denom_dev);
 void k_loss_finalize(spa3d_ctx*, const float* sums, const float* denom_dev, float l1w, float bcew, float* loss3);
@@ -213,3 +216,7 @@ template <typename T> void k_attn_q1_bwd(spa3d_ctx*, const T* q0, int64_t ldq0, 
                                          const float* sq, const float* sk, const float* km, int64_t nseq, int S, int H, int Dh,
                                          const float* p0, const T* d_o0, T* dq0, T* dk, T* dv, float* dsq, float* dsk);
 template <typename T> void k_add_rows_strided(spa3d_ctx*, T* dst, const T* src, int64_t dst_stride_rows, int64_t n, int d);
+// 2-D TRAJAN twin (track_autoencoder.py:117-390)
+template <typename T> void k_vis_mean_pool(spa3d_ctx*, const T* tok, const float* vis, int64_t nseq, int T_, int d, T* out);
+template <typename T> void k_vis_mean_pool_bwd(spa3d_ctx*, const T* dout, const float* vis, int64_t nseq, int T_, int d, T* dtok);
+void k_keymask2d(spa3d_ctx*, const float* visible, const int32_t* boundary, int64_t nseq, int N, int T_, float* km);

@@ -315,9 +315,11 @@ void k_softmax(spa3d_ctx* c, T* s, const float* keymask, int64_t nseq, int H, in
   softmax_kernel<T><<<g, 256, 0, c->stream>>>(s, keymask, nseq, H, Sq, Sk);
   SPA_LAUNCH_CHECK(c);
 }
-// dS = P o (dP - rowsum(dP o P)), in place on dp
+// dS = P o (dP - rowsum(dP o P)), in place on dp; masked keys get exactly 0: where(mask, logit, min) passes them no gradient
+// (this matters only for fully masked rows, where P is uniform instead of 0)
 template <typename T>
-__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ p, T* __restrict__ dp, int64_t rows, int Sk) {
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ p, T* __restrict__ dp, int64_t rows, int Sk,
+                                                          const float* __restrict__ km, int64_t rows_per_seq) {
   const int lane = threadIdx.x & 63;
   int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t stride = (int64_t)gridDim.x * 4;
@@ -326,14 +328,20 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ 
     float s = 0.f;
     for (int k = lane; k < Sk; k += 64) s += ld(pr + k) * ld(dr + k);
     s = wave_sum(s);
-    for (int k = lane; k < Sk; k += 64) { float pv = ld(pr + k); st(dr + k, pv * (ld(dr + k) - s)); }
+    const float* kmr = km ? km + (row / rows_per_seq) * Sk : nullptr;
+    for (int k = lane; k < Sk; k += 64) {
+      float pv = ld(pr + k);
+      float v = pv * (ld(dr + k) - s);
+      if (kmr && kmr[k] == 0.f) v = 0.f;
+      st(dr + k, v);
+    }
   }
 }
 template <typename T>
-void k_softmax_bwd(spa3d_ctx* c, const T* p, T* dp, int64_t rows, int Sk) {
+void k_softmax_bwd(spa3d_ctx* c, const T* p, T* dp, int64_t rows, int Sk, const float* km, int64_t rows_per_seq) {
   if (c->dry || rows == 0) return;
   unsigned g = (unsigned)std::min<int64_t>(cdiv(rows, 4), 65536);
-  softmax_bwd_kernel<T><<<g, 256, 0, c->stream>>>(p, dp, rows, Sk);
+  softmax_bwd_kernel<T><<<g, 256, 0, c->stream>>>(p, dp, rows, Sk, km, rows_per_seq);
   SPA_LAUNCH_CHECK(c);
 }
 
@@ -374,48 +382,50 @@ void k_sin_embed(spa3d_ctx* c, const float* x, int64_t rows, int C, int nf, floa
 // E1+E2 for the track tokens (track_autoencoder_3d.py:126-134): x4 = [x,y,z,t/T] -> sinbuf[nseq*T][4*2nf]
 template <typename T>
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const float* __restrict__ tracks, int64_t nrows, int T_, int nf, float prescale,
-                                                           SinScales sc, T* __restrict__ out) {
-  const int W = 4 * 2 * nf;
+                                                           SinScales sc, T* __restrict__ out, int NC) {
+  const int W = (NC + 1) * 2 * nf;
   const int64_t n = nrows * W;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     int64_t r = i / W; int j = (int)(i - r * W);
     int cc = j / (2 * nf); int f = j - cc * 2 * nf;
     float xv;
-    if (cc < 3) xv = tracks[r * 3 + cc];
+    if (cc < NC) xv = tracks[r * NC + cc];
     else xv = (float)(int)(r % T_) / (float)T_;  // jnp.arange(T)/T
     xv = xv / prescale;
     st(out + i, sin_feat(xv, sc.s[f < nf ? f : f - nf], f >= nf));
   }
 }
 template <typename T>
-void k_embed_tokens(spa3d_ctx* c, const float* tracks, int64_t nrows, int T_, int nf, float prescale, T* sinbuf) {
+void k_embed_tokens(spa3d_ctx* c, const float* tracks, int64_t nrows, int T_, int nf, float prescale, T* sinbuf, int NC) {
   if (c->dry || nrows == 0) return;
-  embed_tokens_kernel<T><<<GRID1D(nrows * 8 * nf, 256), 256, 0, c->stream>>>(tracks, nrows, T_, nf, prescale, make_scales(nf), sinbuf);
+  embed_tokens_kernel<T><<<GRID1D(nrows * (NC + 1) * 2 * nf, 256), 256, 0, c->stream>>>(tracks, nrows, T_, nf, prescale, make_scales(nf), sinbuf, NC);
   SPA_LAUNCH_CHECK(c);
 }
 
 // get_decoder_context + first-level query features (track_autoencoder_3d.py:209-233,265-272):
 // feat[q][0:6nf] = sin-embed(xyz/track_scale); feat[q][6nf] = floor(round(t)/time_scale); qframe = round(t) (half-even)
 __global__ __launch_bounds__(256) void query_embed1_kernel(const float* __restrict__ qp, int64_t nq, int nf, float track_scale,
-                                                           float time_scale, SinScales sc, float* __restrict__ feat, int32_t* __restrict__ qframe) {
-  const int W = 6 * nf + 1;
+                                                           float time_scale, SinScales sc, float* __restrict__ feat, int32_t* __restrict__ qframe,
+                                                           int NC) {
+  const int W = NC * 2 * nf + 1;
   const int64_t n = nq * W;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     int64_t q = i / W; int j = (int)(i - q * W);
-    if (j == 6 * nf) {
-      int32_t fr = (int32_t)rintf(qp[q * 4]);
+    if (j == NC * 2 * nf) {
+      int32_t fr = (int32_t)rintf(qp[q * (NC + 1)]);
       qframe[q] = fr;
       feat[i] = floorf((float)fr / time_scale);
     } else {
       int cc = j / (2 * nf); int f = j - cc * 2 * nf;
-      float xv = qp[q * 4 + 1 + cc] / track_scale;
+      float xv = qp[q * (NC + 1) + 1 + cc] / track_scale;
       feat[i] = sin_feat(xv, sc.s[f < nf ? f : f - nf], f >= nf);
     }
   }
 }
-void k_query_embed1(spa3d_ctx* c, const float* qp, int64_t nq, int nf, float track_scale, float time_scale, float* feat, int32_t* qframe) {
+void k_query_embed1(spa3d_ctx* c, const float* qp, int64_t nq, int nf, float track_scale, float time_scale, float* feat, int32_t* qframe,
+                    int NC) {
   if (c->dry || nq == 0) return;
-  query_embed1_kernel<<<GRID1D(nq * (6 * nf + 1), 256), 256, 0, c->stream>>>(qp, nq, nf, track_scale, time_scale, make_scales(nf), feat, qframe);
+  query_embed1_kernel<<<GRID1D(nq * (NC * 2 * nf + 1), 256), 256, 0, c->stream>>>(qp, nq, nf, track_scale, time_scale, make_scales(nf), feat, qframe, NC);
   SPA_LAUNCH_CHECK(c);
 }
 
@@ -762,20 +772,26 @@ void k_assemble_readout_bwd(spa3d_ctx* c, const T* dseq, const int32_t* qframe, 
 __device__ __forceinline__ float log_sigmoid_f(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
 __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const float* __restrict__ head, int64_t nq, int T_, const float* __restrict__ tgt,
                                                             const float* __restrict__ tvis, float* __restrict__ tracks,
-                                                            float* __restrict__ vlog, float* __restrict__ clog, float* __restrict__ sums) {
+                                                            float* __restrict__ vlog, float* __restrict__ clog, float* __restrict__ sums, int NC) {
+  // head row: NC coordinate blocks of T, then the visibility logits; the 2-D model (NC == 2) has a 4th block: certainty logits
   __shared__ float red[3][4];
   float pn = 0.f, bn = 0.f;
   const int64_t n = nq * T_;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     int64_t q = i / T_; int t = (int)(i - q * T_);
     const float* hr = head + q * 4 * T_;
-    float px = hr[t], py = hr[T_ + t], pz = hr[2 * T_ + t], lg = hr[3 * T_ + t];
-    if (tracks) { tracks[i * 3] = px; tracks[i * 3 + 1] = py; tracks[i * 3 + 2] = pz; }
+    const float lg = hr[NC * T_ + t];
+    float perr = 0.f;
+    for (int cdx = 0; cdx < NC; ++cdx) {
+      const float pv = hr[cdx * T_ + t];
+      if (tracks) tracks[i * NC + cdx] = pv;
+      if (tgt) perr += fabsf(pv - tgt[i * NC + cdx]);
+    }
     if (vlog) vlog[i] = lg;
-    if (clog) clog[i] = 0.f;
+    if (clog) clog[i] = NC == 2 ? hr[3 * T_ + t] : 0.f;  // 3DSPA: certain_logits = zeros (3d:301); TRAJAN: real head (ta:344)
     if (tgt) {
       float y = tvis[i];
-      pn += (fabsf(px - tgt[i * 3]) + fabsf(py - tgt[i * 3 + 1]) + fabsf(pz - tgt[i * 3 + 2])) * y;
+      pn += perr * y;
       bn += -y * log_sigmoid_f(lg) - (1.f - y) * log_sigmoid_f(-lg);
     }
   }
@@ -790,20 +806,22 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const float* __restr
   }
 }
 void k_loss_fwd(spa3d_ctx* c, const float* head, int64_t nq, int T_, const float* tgt, const float* tvis, float* tracks, float* vlog,
-                float* clog, float* sums) {
+                float* clog, float* sums, int NC) {
   if (c->dry || nq == 0) return;
   unsigned g = (unsigned)std::min<int64_t>(cdiv(nq * T_, 256), 4096);
-  head_loss_fwd_kernel<<<g, 256, 0, c->stream>>>(head, nq, T_, tgt, tvis, tracks, vlog, clog, sums);
+  head_loss_fwd_kernel<<<g, 256, 0, c->stream>>>(head, nq, T_, tgt, tvis, tracks, vlog, clog, sums, NC);
   SPA_LAUNCH_CHECK(c);
 }
 // same numerators from already-split predictions (spa3d_loss entry point)
 __global__ __launch_bounds__(256) void loss_from_preds_kernel(const float* __restrict__ tracks, const float* __restrict__ vlog, int64_t n,
-                                                              const float* __restrict__ tgt, const float* __restrict__ tvis, float* sums) {
+                                                              const float* __restrict__ tgt, const float* __restrict__ tvis, float* sums, int NC) {
   __shared__ float red[2][4];
   float pn = 0.f, bn = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float y = tvis[i], lg = vlog[i];
-    pn += (fabsf(tracks[i * 3] - tgt[i * 3]) + fabsf(tracks[i * 3 + 1] - tgt[i * 3 + 1]) + fabsf(tracks[i * 3 + 2] - tgt[i * 3 + 2])) * y;
+    float perr = 0.f;
+    for (int cdx = 0; cdx < NC; ++cdx) perr += fabsf(tracks[i * NC + cdx] - tgt[i * NC + cdx]);
+    pn += perr * y;
     bn += -y * log_sigmoid_f(lg) - (1.f - y) * log_sigmoid_f(-lg);
   }
   pn = wave_sum(pn); bn = wave_sum(bn);
@@ -815,10 +833,11 @@ __global__ __launch_bounds__(256) void loss_from_preds_kernel(const float* __res
     atomicAdd(sums + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
   }
 }
-void k_loss_from_preds(spa3d_ctx* c, const float* tracks, const float* vlog, int64_t n, const float* tgt, const float* tvis, float* sums) {
+void k_loss_from_preds(spa3d_ctx* c, const float* tracks, const float* vlog, int64_t n, const float* tgt, const float* tvis, float* sums,
+                       int NC) {
   if (c->dry || n == 0) return;
   unsigned g = (unsigned)std::min<int64_t>(cdiv(n, 256), 4096);
-  loss_from_preds_kernel<<<g, 256, 0, c->stream>>>(tracks, vlog, n, tgt, tvis, sums);
+  loss_from_preds_kernel<<<g, 256, 0, c->stream>>>(tracks, vlog, n, tgt, tvis, sums, NC);
   SPA_LAUNCH_CHECK(c);
 }
 __global__ __launch_bounds__(256) void vis_count_kernel(const float* __restrict__ v, int64_t n, float* out) {
@@ -855,28 +874,31 @@ void k_loss_finalize(spa3d_ctx* c, const float* sums, const float* denom_dev, fl
 // d head: l1w*sign(pred-tgt)*vis/denom ; bcew*(sigmoid(l)-y)/denom ; sign(0)=0
 template <typename T>
 __global__ void loss_bwd_kernel(const float* __restrict__ head, int64_t nq, int T_, const float* __restrict__ tgt,
-                                const float* __restrict__ tvis, const float* __restrict__ denom_dev, float l1w, float bcew, T* __restrict__ dhead) {
+                                const float* __restrict__ tvis, const float* __restrict__ denom_dev, float l1w, float bcew, T* __restrict__ dhead,
+                                int NC) {
   const float inv = 1.f / *denom_dev;
   const int64_t n = nq * 4 * T_;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     int64_t q = i / (4 * T_); int j = (int)(i - q * 4 * T_);
     int cc = j / T_, t = j - cc * T_;
     float y = tvis[q * T_ + t], g;
-    if (cc < 3) {
-      float df = head[i] - tgt[(q * T_ + t) * 3 + cc];
+    if (cc < NC) {
+      float df = head[i] - tgt[(q * T_ + t) * NC + cc];
       g = l1w * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * y * inv;
-    } else {
+    } else if (cc == NC) {
       float l = head[i];
       g = bcew * (1.f / (1.f + expf(-l)) - y) * inv;
+    } else {
+      g = 0.f;  // TRAJAN's certainty head carries no loss term in compute_loss_2d (train.py:60-93)
     }
     st(dhead + i, g);
   }
 }
 template <typename T>
 void k_loss_bwd(spa3d_ctx* c, const float* head, int64_t nq, int T_, const float* tgt, const float* tvis, const float* denom_dev, float l1w,
-                float bcew, T* dhead) {
+                float bcew, T* dhead, int NC) {
   if (c->dry || nq == 0) return;
-  loss_bwd_kernel<T><<<GRID1D(nq * 4 * T_, 256), 256, 0, c->stream>>>(head, nq, T_, tgt, tvis, denom_dev, l1w, bcew, dhead);
+  loss_bwd_kernel<T><<<GRID1D(nq * 4 * T_, 256), 256, 0, c->stream>>>(head, nq, T_, tgt, tvis, denom_dev, l1w, bcew, dhead, NC);
   SPA_LAUNCH_CHECK(c);
 }
 
@@ -958,9 +980,9 @@ void k_uniform_noise(spa3d_ctx* c, float* out, int64_t n, uint32_t k0, uint32_t 
   template void k_rmsnorm_heads_bwd<T>(spa3d_ctx*, const T*, int64_t, const float*, const T*, int64_t, T*, int64_t, float*, int64_t,   \
                                        int, int);                                                                                     \
   template void k_softmax<T>(spa3d_ctx*, T*, const float*, int64_t, int, int, int);                                                    \
-  template void k_softmax_bwd<T>(spa3d_ctx*, const T*, T*, int64_t, int);                                                              \
+  template void k_softmax_bwd<T>(spa3d_ctx*, const T*, T*, int64_t, int, const float*, int64_t);                                                              \
   template void k_sin_embed<T>(spa3d_ctx*, const float*, int64_t, int, int, float, T*);                                                \
-  template void k_embed_tokens<T>(spa3d_ctx*, const float*, int64_t, int, int, float, T*);                                             \
+  template void k_embed_tokens<T>(spa3d_ctx*, const float*, int64_t, int, int, float, T*, int);                                           \
   template void k_colsum<T>(spa3d_ctx*, const T*, int64_t, int, int64_t, float*, int, int);                                                    \
   template void k_gelu<T>(spa3d_ctx*, const T*, T*, int64_t);                                                                          \
   template void k_add<T>(spa3d_ctx*, T*, const T*, int64_t);                                                                           \
@@ -976,7 +998,7 @@ void k_uniform_noise(spa3d_ctx* c, float* out, int64_t n, uint32_t k0, uint32_t 
   template void k_bcast_grad<T>(spa3d_ctx*, const T*, int64_t, int64_t, int64_t, float*);                                              \
   template void k_assemble_readout<T>(spa3d_ctx*, const T*, const T*, const int32_t*, int64_t, int, int, int, int, T*);                \
   template void k_assemble_readout_bwd<T>(spa3d_ctx*, const T*, const int32_t*, int64_t, int, int, int, int, T*, float*);              \
-  template void k_loss_bwd<T>(spa3d_ctx*, const float*, int64_t, int, const float*, const float*, const float*, float, float, T*);
+  template void k_loss_bwd<T>(spa3d_ctx*, const float*, int64_t, int, const float*, const float*, const float*, float, float, T*, int);
 INST(float)
 INST(bf16_t)
 
@@ -1295,3 +1317,53 @@ template <typename T> void k_add_rows_strided(spa3d_ctx* c, T* dst, const T* src
   template void k_add_rows_strided<T>(spa3d_ctx*, T*, const T*, int64_t, int64_t, int);
 INST_Q1(float)
 INST_Q1(bf16_t)
+
+// ---------------------------------------------------------------------------------------------
+// TRAJAN track pooling (track_autoencoder.py:230-232): mean of the frame tokens over VISIBLE frames
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void vis_mean_pool_kernel(const T* __restrict__ tok, const float* __restrict__ vis, int64_t nseq, int T_, int d, T* __restrict__ out) {
+  const int64_t tot = nseq * d;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    int64_t s_ = i / d; int j = (int)(i - s_ * d);
+    float a = 0.f, cnt = 0.f;
+    for (int t = 0; t < T_; ++t) { const float v = vis[s_ * T_ + t] != 0.f ? 1.f : 0.f; a += ld(tok + (s_ * T_ + t) * d + j) * v; cnt += v; }
+    st(out + i, a / fmaxf(1.f, cnt));
+  }
+}
+template <typename T> void k_vis_mean_pool(spa3d_ctx* c, const T* tok, const float* vis, int64_t nseq, int T_, int d, T* out) {
+  if (c->dry || nseq == 0) return;
+  vis_mean_pool_kernel<T><<<GRID1D(nseq * d, 256), 256, 0, c->stream>>>(tok, vis, nseq, T_, d, out); SPA_LAUNCH_CHECK(c);
+}
+template <typename T>
+__global__ void vis_mean_pool_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ vis, int64_t nseq, int T_, int d, T* __restrict__ dtok) {
+  const int64_t tot = nseq * T_ * d;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    int64_t r = i / d; int j = (int)(i - r * d);
+    int64_t s_ = r / T_;
+    float cnt = 0.f;
+    for (int t = 0; t < T_; ++t) cnt += vis[s_ * T_ + t] != 0.f ? 1.f : 0.f;
+    const float v = vis[r] != 0.f ? 1.f : 0.f;
+    st(dtok + i, ld(dout + s_ * d + j) * v / fmaxf(1.f, cnt));
+  }
+}
+template <typename T> void k_vis_mean_pool_bwd(spa3d_ctx* c, const T* dout, const float* vis, int64_t nseq, int T_, int d, T* dtok) {
+  if (c->dry || nseq == 0) return;
+  vis_mean_pool_bwd_kernel<T><<<GRID1D(nseq * T_ * d, 256), 256, 0, c->stream>>>(dout, vis, nseq, T_, d, dtok); SPA_LAUNCH_CHECK(c);
+}
+// key mask of the 2-D model (ta:217-223): km[seq][t] = visible & (t < boundary), no readout key
+__global__ void keymask2d_kernel(const float* __restrict__ vis, const int32_t* __restrict__ boundary, int64_t nseq, int N, int T_, float* km) {
+  const int64_t n = nseq * T_;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    int64_t s_ = i / T_; int t = (int)(i - s_ * T_);
+    km[i] = (vis[i] != 0.f && t < boundary[s_ / N]) ? 1.f : 0.f;
+  }
+}
+void k_keymask2d(spa3d_ctx* c, const float* visible, const int32_t* boundary, int64_t nseq, int N, int T_, float* km) {
+  if (c->dry || nseq == 0) return;
+  keymask2d_kernel<<<GRID1D(nseq * T_, 256), 256, 0, c->stream>>>(visible, boundary, nseq, N, T_, km); SPA_LAUNCH_CHECK(c);
+}
+template void k_vis_mean_pool<float>(spa3d_ctx*, const float*, const float*, int64_t, int, int, float*);
+template void k_vis_mean_pool<bf16_t>(spa3d_ctx*, const bf16_t*, const float*, int64_t, int, int, bf16_t*);
+template void k_vis_mean_pool_bwd<float>(spa3d_ctx*, const float*, const float*, int64_t, int, int, float*);
+template void k_vis_mean_pool_bwd<bf16_t>(spa3d_ctx*, const bf16_t*, const float*, int64_t, int, int, bf16_t*);

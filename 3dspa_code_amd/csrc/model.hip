@@ -60,9 +60,11 @@ static void add_xf(spa3d_ctx* c, const std::string& p, int d, int mlp, int L, in
 static void build_leaves(spa3d_ctx* c) {
   const spa3d_config& g = c->cfg;
   const int d = g.track_token_dim, dl = g.encoder_latent_dim, dd = g.decoder_num_channels, nf = g.num_frequencies;
+  const int NC = g.model_kind == 1 ? 2 : 3;
   add_leaf(c, "initializer/state_init", {g.num_latent_tokens, dl});
-  add_leaf(c, "input_readout_token/state_init", {1, d});
-  add_leaf(c, "track_token_projection/kernel", {4 * 2 * nf, d});
+  // TRAJAN declares input_readout_token in setup() but never calls it (track_autoencoder.py:147), so Flax creates no parameter
+  if (g.model_kind == 0) add_leaf(c, "input_readout_token/state_init", {1, d});
+  add_leaf(c, "track_token_projection/kernel", {(NC + 1) * 2 * nf, d});
   add_leaf(c, "track_token_projection/bias", {d});
   if (g.dino_feature_dim > 0) {
     add_leaf(c, "dino_projection/kernel", {g.dino_feature_dim, d});  // repair R4
@@ -80,7 +82,7 @@ static void build_leaves(spa3d_ctx* c) {
   add_leaf(c, "decompressor/bias", {dd - 128});
   add_xf(c, "decompress_attn", dd - 128, g.dec_mlp, g.dec_layers, 0);
   add_xf(c, "track_readout_attn", dd, g.ro_mlp, g.ro_layers, 0);
-  const int qin = (3 * 2 * nf + 1) * 2 * nf;
+  const int qin = (NC * 2 * nf + 1) * 2 * nf;
   add_leaf(c, "query_encoder/kernel", {qin, dd});
   add_leaf(c, "query_encoder/bias", {dd});
   add_leaf(c, "track_predictor/kernel", {dd, 4 * g.num_output_frames});
@@ -115,7 +117,7 @@ template <typename T> struct BlockStash {
 template <typename T> struct Net {
   spa3d_ctx* c; const spa3d_config& g; const float* P; float* G;
   std::map<std::string, int64_t> off;
-  int H, Dh, E;
+  int H, Dh, E, NC; bool twoD;
   Lin<T> tok, dino, depth, comp, decomp, qenc, pred;
   XfW<T> enc, t2l, dec, ro;
   const float *lat0, *readout; float *g_lat0, *g_readout;
@@ -124,6 +126,7 @@ template <typename T> struct Net {
   Net(spa3d_ctx* c_, const float* P_, float* G_) : c(c_), g(c_->cfg), P(P_), G(G_) {
     for (auto& l : c->leaves) off[l.name] = l.offset;
     H = g.num_heads; Dh = g.qkv_size / H; E = g.qkv_size;
+    twoD = g.model_kind == 1; NC = twoD ? 2 : 3;
   }
   template <typename U> U* alloc(int64_t n) { return (U*)c->ar.alloc(n * (int64_t)sizeof(U)); }
   const float* p(const std::string& n) { return P + off.at(n); }
@@ -178,8 +181,9 @@ template <typename T> struct Net {
     zero_page = c->ar.alloc(256); k_zero(c, zero_page, 256);
     const int d = g.track_token_dim, dl = g.encoder_latent_dim, dd = g.decoder_num_channels, nf = g.num_frequencies;
     lat0 = p("initializer/state_init"); g_lat0 = gr("initializer/state_init");
-    readout = p("input_readout_token/state_init"); g_readout = gr("input_readout_token/state_init");
-    tok = make_lin({"track_token_projection/kernel"}, "track_token_projection/bias", 8 * nf, d);
+    readout = nullptr; g_readout = nullptr;
+    if (!twoD) { readout = p("input_readout_token/state_init"); g_readout = gr("input_readout_token/state_init"); }
+    tok = make_lin({"track_token_projection/kernel"}, "track_token_projection/bias", (NC + 1) * 2 * nf, d);
     if (g.dino_feature_dim > 0) dino = make_lin({"dino_projection/kernel"}, "dino_projection/bias", g.dino_feature_dim, d);
     if (g.depth_feature_dim > 0) depth = make_lin({"depth_projection/kernel"}, "depth_projection/bias", g.depth_feature_dim, d);
     enc = make_xf("input_track_transformer", d, g.enc_mlp, g.enc_layers, 0);
@@ -188,7 +192,7 @@ template <typename T> struct Net {
     decomp = make_lin({"decompressor/kernel"}, "decompressor/bias", g.latent_token_dim, dd - 128);
     dec = make_xf("decompress_attn", dd - 128, g.dec_mlp, g.dec_layers, 0);
     ro = make_xf("track_readout_attn", dd, g.ro_mlp, g.ro_layers, 0);
-    qenc = make_lin({"query_encoder/kernel"}, "query_encoder/bias", (6 * nf + 1) * 2 * nf, dd);
+    qenc = make_lin({"query_encoder/kernel"}, "query_encoder/bias", (NC * 2 * nf + 1) * 2 * nf, dd);
     pred = make_lin({"track_predictor/kernel"}, "track_predictor/bias", dd, 4 * g.num_output_frames);
   }
 
@@ -378,7 +382,7 @@ template <typename T> struct Net {
     int64_t Bc, nseq; int N, Q, T_, S;
     // encoder
     T* sinbuf; const void* dino; const void* depthf; float* km; T* tok0; std::vector<BlockStash<T>> enc_st; T* enc_last; T* r0; float* st_r0;
-    T* enc_out; LastStash enc_lst, ro_lst;
+    T* enc_out; LastStash enc_lst, ro_lst; T* enc_ln_all = nullptr; float* st_all = nullptr; const float* sup_vis = nullptr;
     // t2l
     T* lat_in; std::vector<BlockStash<T>> t2l_st; T* t2l_last; float* st_t2l; T* t2l_n; float* latents;  // [Bc,L,Ld] f32
     // decode
@@ -391,38 +395,52 @@ template <typename T> struct Net {
   void encode_chunk(Chunk& k, const spa3d_batch* b, int64_t b0, bool train) {
     const int d = g.track_token_dim, nf = g.num_frequencies, T_ = k.T_, S = k.S;
     const int64_t nseq = k.nseq;
-    const float* tracks = b->support_tracks + b0 * k.N * T_ * 3;
-    k.sinbuf = alloc<T>(nseq * T_ * 8 * nf);
-    k_embed_tokens<T>(c, tracks, nseq * T_, T_, nf, g.track_scale_factor, k.sinbuf);                 // 3d:126-134
+    const float* tracks = b->support_tracks + b0 * k.N * T_ * NC;
+    k.sup_vis = b->support_tracks_visible + b0 * k.N * T_;
+    k.sinbuf = alloc<T>(nseq * T_ * (NC + 1) * 2 * nf);
+    k_embed_tokens<T>(c, tracks, nseq * T_, T_, nf, g.track_scale_factor, k.sinbuf, NC);             // 3d:126-134 / ta:186-199
     k.tok0 = alloc<T>(nseq * S * d);
-    // rows 1..T of every sequence <- Dense(sin) [+ Dense(dino)] [+ Dense(depth)]                      3d:137-147
-    lin_fwd(tok, k.sinbuf, k.tok0, nseq * T_, EPI_NONE, nullptr, 0, 0, 0, 0, T_, 1);
+    // 3DSPA: rows 1..T of every sequence <- Dense(sin) [+ Dense(dino)] [+ Dense(depth)] (3d:137-147); TRAJAN: rows 0..T-1 (ta:211)
+    const int cg = twoD ? 0 : T_, cs = twoD ? 0 : 1;
+    lin_fwd(tok, k.sinbuf, k.tok0, nseq * T_, EPI_NONE, nullptr, 0, 0, 0, 0, cg, cs);
     k.dino = nullptr; k.depthf = nullptr;
-    if (g.dino_feature_dim > 0 && b->dino_features) {
+    if (!twoD && g.dino_feature_dim > 0 && b->dino_features) {
       k.dino = (const T*)b->dino_features + b0 * k.N * T_ * g.dino_feature_dim;
       lin_fwd(dino, (const T*)k.dino, k.tok0, nseq * T_, EPI_NONE, nullptr, 0, 1, 0, 0, T_, 1);
     }
-    if (g.depth_feature_dim > 0 && b->depth_features) {
+    if (!twoD && g.depth_feature_dim > 0 && b->depth_features) {
       k.depthf = (const T*)b->depth_features + b0 * k.N * T_ * g.depth_feature_dim;
       lin_fwd(depth, (const T*)k.depthf, k.tok0, nseq * T_, EPI_NONE, nullptr, 0, 1, 0, 0, T_, 1);
     }
-    k_set_readout_rows<T>(c, k.tok0, readout, nseq, S, d);                                           // 3d:161-165
     k.km = alloc<float>(nseq * S);
-    k_keymask(c, b->support_tracks_visible + b0 * k.N * T_, b->boundary_frame + b0, nseq, k.N, T_, k.km);  // 3d:167-180 (R2,R3)
+    if (twoD) {
+      k_keymask2d(c, k.sup_vis, b->boundary_frame + b0, nseq, k.N, T_, k.km);                        // ta:213-223
+    } else {
+      k_set_readout_rows<T>(c, k.tok0, readout, nseq, S, d);                                         // 3d:161-165
+      k_keymask(c, k.sup_vis, b->boundary_frame + b0, nseq, k.N, T_, k.km);                          // 3d:167-180 (R2,R3)
+    }
     const T* x = k.tok0;
     const int nenc = (int)enc.blocks.size();
+    const int nfull = twoD ? nenc : nenc - 1;  // TRAJAN pools over every frame token: no pruned last block
     k.enc_st.resize(nenc);
     T* pp[2] = {nullptr, nullptr};
-    if (!train && nenc > 1) { pp[0] = alloc<T>(nseq * S * d); if (nenc > 2) pp[1] = alloc<T>(nseq * S * d); }
-    for (int i = 0; i + 1 < nenc; ++i) {
+    if (!train && nfull > 0) { pp[0] = alloc<T>(nseq * S * d); if (nfull > 1) pp[1] = alloc<T>(nseq * S * d); }
+    for (int i = 0; i < nfull; ++i) {
       T* y = train ? alloc<T>(nseq * S * d) : pp[i & 1];
       block_fwd(enc.blocks[i], x, y, nseq, S, k.km, nullptr, 0, train ? &k.enc_st[i] : nullptr);
       x = y;
     }
     k.enc_last = const_cast<T*>(x);
-    k.r0 = alloc<T>(nseq * d); k.st_r0 = alloc<float>(nseq * 2); k.enc_out = alloc<T>(nseq * d);
-    block_fwd_last(enc.blocks[nenc - 1], x, k.r0, nseq, S, k.km, train ? &k.enc_lst : nullptr);     // token 0 only: 3d:187-188
-    k_layernorm<T>(c, k.r0, enc.norm_enc, k.enc_out, k.st_r0, nseq, d);                              // attention.py:49-51 (row 0 only)
+    k.enc_out = alloc<T>(nseq * d);
+    if (twoD) {
+      k.enc_ln_all = alloc<T>(nseq * S * d); k.st_all = alloc<float>(nseq * S * 2);
+      k_layernorm<T>(c, x, enc.norm_enc, k.enc_ln_all, k.st_all, nseq * S, d);                       // attention.py:49-51
+      k_vis_mean_pool<T>(c, k.enc_ln_all, k.sup_vis, nseq, T_, d, k.enc_out);                        // ta:230-232
+    } else {
+      k.r0 = alloc<T>(nseq * d); k.st_r0 = alloc<float>(nseq * 2);
+      block_fwd_last(enc.blocks[nenc - 1], x, k.r0, nseq, S, k.km, train ? &k.enc_lst : nullptr);    // token 0 only: 3d:187-188
+      k_layernorm<T>(c, k.r0, enc.norm_enc, k.enc_out, k.st_r0, nseq, d);                            // attention.py:49-51 (row 0 only)
+    }
     // L1-L3
     const int L = g.num_latent_tokens, dl = g.encoder_latent_dim;
     k.lat_in = alloc<T>(k.Bc * L * dl);
@@ -461,9 +479,9 @@ template <typename T> struct Net {
     k.st_dec = alloc<float>(nl * 2); k.latd = alloc<T>(nl * Cl);
     k_layernorm<T>(c, x, dec.norm_enc, k.latd, k.st_dec, nl, Cl);
     // query tokens                                                                                     3d:209-233,265-275
-    const int F = 6 * nf + 1;
+    const int F = NC * 2 * nf + 1;
     k.feat = alloc<float>(nq * F); k.qframe = alloc<int32_t>(nq);
-    k_query_embed1(c, b->query_points + b0 * k.Q * 4, nq, nf, g.track_scale_factor, g.time_scale_factor, k.feat, k.qframe);
+    k_query_embed1(c, b->query_points + b0 * k.Q * (NC + 1), nq, nf, g.track_scale_factor, g.time_scale_factor, k.feat, k.qframe, NC);
     k.sin2 = alloc<T>(nq * F * 2 * nf);
     k_sin_embed<T>(c, k.feat, nq, F, nf, g.track_scale_factor, k.sin2);
     k.qtok = alloc<T>(nq * dd);
@@ -502,8 +520,8 @@ template <typename T> struct Net {
       const int S = L + 1;
       const int64_t mk = c->ar.mark();
       T* dhead = alloc<T>(nq * 4 * To);
-      k_loss_bwd<T>(c, k.head, nq, To, b->query_tracks + b0 * k.Q * To * 3, b->query_tracks_visible + b0 * k.Q * To, denom_dev,
-                    L1_WEIGHT, BCE_WEIGHT, dhead);
+      k_loss_bwd<T>(c, k.head, nq, To, b->query_tracks + b0 * k.Q * To * NC, b->query_tracks_visible + b0 * k.Q * To, denom_dev,
+                    L1_WEIGHT, BCE_WEIGHT, dhead, NC);
       lin_bwd_w(pred, k.q0n, dhead, nq);
       T* dq0n = alloc<T>(nq * dd);
       lin_bwd_x(pred, dhead, dq0n, nq);
@@ -547,18 +565,27 @@ template <typename T> struct Net {
     k_bcast_grad<T>(c, dt2l, (int64_t)L * dl, k.Bc, (int64_t)L * dl, g_lat0);
     // ---- track encoder
     const int S = k.S;
-    T* dr0 = alloc<T>(nseq * d);
-    k_layernorm_bwd<T>(c, k.r0, enc.norm_enc, k.st_r0, denc_out, dr0, enc.g_norm_enc, nseq, d, nullptr);
     T* dtok = alloc<T>(nseq * S * d);
     const int nenc = (int)enc.blocks.size();
-    block_bwd_last(enc.blocks[nenc - 1], k.enc_lst, dr0, dtok, nseq, S, k.km);
-    for (int i = nenc - 2; i >= 0; --i)
-      block_bwd(enc.blocks[i], k.enc_st[i], dtok, dtok, nseq, S, k.km, nullptr, 0, nullptr);
-    k_bcast_grad<T>(c, dtok, d, nseq, (int64_t)S * d, g_readout);
-    // token rows 1..T of every sequence (row remap on the reduction index: no compaction copy)
-    lin_bwd_w(tok, k.sinbuf, dtok, nseq * T_, 0, T_, 1);
-    if (k.dino) lin_bwd_w(dino, (const T*)k.dino, dtok, nseq * T_, 0, T_, 1);
-    if (k.depthf) lin_bwd_w(depth, (const T*)k.depthf, dtok, nseq * T_, 0, T_, 1);
+    if (twoD) {
+      T* dln = alloc<T>(nseq * S * d);
+      k_vis_mean_pool_bwd<T>(c, denc_out, k.sup_vis, nseq, T_, d, dln);
+      k_layernorm_bwd<T>(c, k.enc_last, enc.norm_enc, k.st_all, dln, dtok, enc.g_norm_enc, nseq * S, d, nullptr);
+      for (int i = nenc - 1; i >= 0; --i)
+        block_bwd(enc.blocks[i], k.enc_st[i], dtok, dtok, nseq, S, k.km, nullptr, 0, nullptr);
+      lin_bwd_w(tok, k.sinbuf, dtok, nseq * T_);
+    } else {
+      T* dr0 = alloc<T>(nseq * d);
+      k_layernorm_bwd<T>(c, k.r0, enc.norm_enc, k.st_r0, denc_out, dr0, enc.g_norm_enc, nseq, d, nullptr);
+      block_bwd_last(enc.blocks[nenc - 1], k.enc_lst, dr0, dtok, nseq, S, k.km);
+      for (int i = nenc - 2; i >= 0; --i)
+        block_bwd(enc.blocks[i], k.enc_st[i], dtok, dtok, nseq, S, k.km, nullptr, 0, nullptr);
+      k_bcast_grad<T>(c, dtok, d, nseq, (int64_t)S * d, g_readout);
+      // token rows 1..T of every sequence (row remap on the reduction index: no compaction copy)
+      lin_bwd_w(tok, k.sinbuf, dtok, nseq * T_, 0, T_, 1);
+      if (k.dino) lin_bwd_w(dino, (const T*)k.dino, dtok, nseq * T_, 0, T_, 1);
+      if (k.depthf) lin_bwd_w(depth, (const T*)k.depthf, dtok, nseq * T_, 0, T_, 1);
+    }
     c->ar.release(mk0);
   }
 };
@@ -596,7 +623,7 @@ static void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
   }
   for (int64_t b0 = 0; b0 < b->B; b0 += Bc) {
     typename Net<T>::Chunk k{};
-    k.Bc = std::min<int64_t>(Bc, b->B - b0); k.N = b->N; k.Q = b->Q; k.T_ = b->T; k.S = b->T + 1; k.nseq = k.Bc * b->N;
+    k.Bc = std::min<int64_t>(Bc, b->B - b0); k.N = b->N; k.Q = b->Q; k.T_ = b->T; k.S = b->T + (g.model_kind == 1 ? 0 : 1); k.nseq = k.Bc * b->N;
     const int64_t mk = c->ar.mark();
     const float* lat = nullptr;
     if (a.mode != MODE_DECODE) {
@@ -610,11 +637,12 @@ static void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
     if (a.mode != MODE_ENCODE) {
       net.decode_chunk(k, b, b0, lat, noise, train);
       const int64_t nq = k.Bc * k.Q;
-      float* tr = a.out && a.out->tracks ? a.out->tracks + b0 * b->Q * To * 3 : nullptr;
+      const int NC = net.NC;
+      float* tr = a.out && a.out->tracks ? a.out->tracks + b0 * b->Q * To * NC : nullptr;
       float* vl = a.out && a.out->visible_logits ? a.out->visible_logits + b0 * b->Q * To : nullptr;
       float* cl = a.out && a.out->certain_logits ? a.out->certain_logits + b0 * b->Q * To : nullptr;
-      k_loss_fwd(c, k.head, nq, To, train ? b->query_tracks + b0 * b->Q * To * 3 : nullptr,
-                 train ? b->query_tracks_visible + b0 * b->Q * To : nullptr, tr, vl, cl, sums);
+      k_loss_fwd(c, k.head, nq, To, train ? b->query_tracks + b0 * b->Q * To * NC : nullptr,
+                 train ? b->query_tracks_visible + b0 * b->Q * To : nullptr, tr, vl, cl, sums, NC);
       if (train) net.backward_chunk(k, b, b0, denom_dev);
     }
     c->ar.release(mk);
@@ -681,6 +709,8 @@ int spa3d_create(const spa3d_config* cfg, spa3d_handle* out) {
   if (cfg->num_heads <= 0 || cfg->qkv_size % cfg->num_heads) return SPA3D_ERR_ARG;  // attention.py:147-150
   if (cfg->qkv_size / cfg->num_heads > 128 || cfg->num_frequencies > 64 || cfg->num_frequencies <= 0) return SPA3D_ERR_ARG;
   if (cfg->precision != SPA3D_F32 && cfg->precision != SPA3D_BF16) return SPA3D_ERR_ARG;
+  if (cfg->model_kind != 0 && cfg->model_kind != 1) return SPA3D_ERR_ARG;
+  if (cfg->model_kind == 1 && (cfg->dino_feature_dim != 0 || cfg->depth_feature_dim != 0)) return SPA3D_ERR_ARG;
   if (cfg->track_token_dim > 2048 || cfg->decoder_num_channels > 2048 || cfg->encoder_latent_dim > 2048) return SPA3D_ERR_ARG;
   spa3d_ctx* c = new (std::nothrow) spa3d_ctx();
   if (!c) return SPA3D_ERR_ARG;
@@ -752,7 +782,7 @@ int spa3d_loss(spa3d_handle h, const spa3d_batch* b, const spa3d_outputs* preds,
   k_zero(h, scratch, 32);
   k_vis_count(h, b->query_tracks_visible, n, scratch + 2);
   k_set_denom(h, scratch, denom, scratch + 4);
-  k_loss_from_preds(h, preds->tracks, preds->visible_logits, n, b->query_tracks, b->query_tracks_visible, scratch);
+  k_loss_from_preds(h, preds->tracks, preds->visible_logits, n, b->query_tracks, b->query_tracks_visible, scratch, h->cfg.model_kind == 1 ? 2 : 3);
   k_loss_finalize(h, scratch, scratch + 4, L1_WEIGHT, BCE_WEIGHT, loss3);
   return h->hip_err ? SPA3D_ERR_HIP : SPA3D_OK;
 }

@@ -124,6 +124,7 @@ class TrackAutoEncoder3D:
       raise ValueError(f'self.num_heads={self.num_heads} must divide self.qk_size={self.qkv_size}.')
     self._handles: Dict[Any, Any] = {}
     self._ws: Optional[torch.Tensor] = None
+    self._kind, self._nc = 0, 3  # 0: 3DSPA (x,y,z); the 2-D TRAJAN subclass sets (1, 2)
     self._ws_cap = 0  # size of a budget-limited workspace (0: none / large enough for every request so far)
 
   # -------------------------------------------------------------------------------- handles / layout
@@ -139,7 +140,7 @@ class TrackAutoEncoder3D:
                         self.track_scale_factor, self.time_scale_factor, self.track_token_dim, self.encoder_latent_dim,
                         self.decoder_num_channels, dino_dim, depth_dim, self.num_heads, self.qkv_size, self.enc_mlp,
                         self.enc_layers, self.t2l_mlp, self.t2l_layers, self.dec_mlp, self.dec_layers, self.ro_mlp,
-                        self.ro_layers, _lib.BF16 if self.precision == 'bf16' else _lib.F32)
+                        self.ro_layers, _lib.BF16 if self.precision == 'bf16' else _lib.F32, self._kind)
       h = C.c_void_p()
       _lib.check(lib.spa3d_create(C.byref(cfg), C.byref(h)), what='spa3d_create')
       leaves = []
@@ -242,8 +243,8 @@ class TrackAutoEncoder3D:
         raise KeyError('inputs need support_tracks, support_tracks_visible and boundary_frame')
       st = self._f32(st, 'support_tracks')
       vis = self._f32(inputs['support_tracks_visible'], 'support_tracks_visible')
-      if st.dim() != 4 or st.shape[-1] != 3:
-        raise ValueError(f'support_tracks must be [B,N,T,3], got {tuple(st.shape)}')
+      if st.dim() != 4 or st.shape[-1] != self._nc:
+        raise ValueError(f'support_tracks must be [B,N,T,{self._nc}], got {tuple(st.shape)}')
       if tuple(vis.shape[:3]) != tuple(st.shape[:3]):
         raise ValueError('support_tracks_visible must be [B,N,T,1]')
       bf = inputs['boundary_frame']
@@ -269,8 +270,8 @@ class TrackAutoEncoder3D:
       if qp is None:
         qp = self.default_query_grid(inputs['support_tracks'])
       qp = self._f32(qp, 'query_points')
-      if qp.dim() != 3 or qp.shape[-1] != 4:
-        raise ValueError(f'query_points must be [B,Q,4], got {tuple(qp.shape)}')
+      if qp.dim() != 3 or qp.shape[-1] != self._nc + 1:
+        raise ValueError(f'query_points must be [B,Q,{self._nc + 1}], got {tuple(qp.shape)}')
       if need_support and qp.shape[0] != b.B:
         raise ValueError('query_points batch dimension does not match support_tracks')
       keep.append(qp)
@@ -290,8 +291,8 @@ class TrackAutoEncoder3D:
       To = self.num_output_frames
       qt = self._f32(inputs['query_tracks'], 'query_tracks')
       qv = self._f32(inputs['query_tracks_visible'], 'query_tracks_visible')
-      if tuple(qt.shape) != (b.B, b.Q, To, 3) or tuple(qv.shape[:3]) != (b.B, b.Q, To):
-        raise ValueError(f'query_tracks must be {(b.B, b.Q, To, 3)} and query_tracks_visible {(b.B, b.Q, To, 1)}')
+      if tuple(qt.shape) != (b.B, b.Q, To, self._nc) or tuple(qv.shape[:3]) != (b.B, b.Q, To):
+        raise ValueError(f'query_tracks must be {(b.B, b.Q, To, self._nc)} and query_tracks_visible {(b.B, b.Q, To, 1)}')
       keep += [qt, qv]
       b.query_tracks, b.query_tracks_visible = qt.data_ptr(), qv.data_ptr()
     return b, keep
@@ -301,7 +302,8 @@ class TrackAutoEncoder3D:
     dev = support_tracks.device
     g = torch.arange(32, dtype=torch.float32, device=dev) / 32.0 + 1.0 / 64.0
     qx, qy = torch.meshgrid(g, g, indexing='xy')
-    q = torch.stack([torch.zeros_like(qx), qx, qy, torch.zeros_like(qx)], dim=-1).reshape(-1, 4)
+    cols = [torch.zeros_like(qx), qx, qy] + ([torch.zeros_like(qx)] if self._nc == 3 else [])  # z = 0 in 3-D (3d:218)
+    q = torch.stack(cols, dim=-1).reshape(-1, self._nc + 1)
     return q[None].expand(support_tracks.shape[0], -1, -1).contiguous()
 
   # -------------------------------------------------------------------------------- workspace
@@ -366,7 +368,7 @@ class TrackAutoEncoder3D:
   def _alloc_outputs(self, B, Q, dev):
     To = self.num_output_frames
     res = TrackAutoEncoderResults(
-        torch.empty(B, Q, To, 3, dtype=torch.float32, device=dev), torch.empty(B, Q, To, 1, dtype=torch.float32, device=dev),
+        torch.empty(B, Q, To, self._nc, dtype=torch.float32, device=dev), torch.empty(B, Q, To, 1, dtype=torch.float32, device=dev),
         torch.empty(B, Q, To, 1, dtype=torch.float32, device=dev))
     out = _lib.Outputs(res.tracks.data_ptr(), res.visible_logits.data_ptr(), res.certain_logits.data_ptr(), None)
     return res, out
@@ -428,7 +430,7 @@ def compute_loss_3d(predictions: TrackAutoEncoderResults, targets, l1_weight: fl
   tr = predictions.tracks
   _require_cuda(tr, 'predictions.tracks')
   B, Q, To = tr.shape[:3]
-  h = _loss_handle(To)
+  h = _loss_handle(To, 1 if tr.shape[-1] == 2 else 0)
   b = _lib.Batch()
   b.B, b.Q = B, Q
   qt = targets['query_tracks'].to(torch.float32).contiguous()
@@ -445,14 +447,44 @@ def compute_loss_3d(predictions: TrackAutoEncoderResults, targets, l1_weight: fl
   return {'total_loss': l1_weight * pos + bce_weight * vis, 'position_loss': pos, 'visible_loss': vis}
 
 
-_LOSS_HANDLES: Dict[int, Any] = {}
+_LOSS_HANDLES: Dict[Any, Any] = {}
 
 
-def _loss_handle(num_output_frames):
-  if num_output_frames not in _LOSS_HANDLES:
-    m = TrackAutoEncoder3D(num_output_frames=num_output_frames, use_dino=False, use_depth=False, precision='fp32')
-    _LOSS_HANDLES[num_output_frames] = m._handle(0, 0)[0]
-  return _LOSS_HANDLES[num_output_frames]
+def _loss_handle(num_output_frames, kind=0):
+  if (num_output_frames, kind) not in _LOSS_HANDLES:
+    cls = TrackAutoEncoder if kind else TrackAutoEncoder3D
+    m = cls(num_output_frames=num_output_frames, precision='fp32') if kind else cls(num_output_frames=num_output_frames, use_dino=False,
+                                                                                    use_depth=False, precision='fp32')
+    _LOSS_HANDLES[(num_output_frames, kind)] = m._handle(0, 0)[0]
+  return _LOSS_HANDLES[(num_output_frames, kind)]
+
+
+def compute_loss_2d(predictions: TrackAutoEncoderResults, targets, l1_weight: float = 5000.0, bce_weight: float = 1e-8, denom: float = 0.0):
+  """train.py:60-93 (same arithmetic as compute_loss_3d on 2 coordinates)."""
+  return compute_loss_3d(predictions, targets, l1_weight, bce_weight, denom)
+
+
+class TrackAutoEncoder(TrackAutoEncoder3D):
+  """Drop-in for the 2-D TRAJAN twin track_autoencoder.TrackAutoEncoder (track_autoencoder.py:117-390): (x,y) tracks,
+  no readout token (frame tokens are mean-pooled over visible frames, :230-232), a real certainty head (:344), no DINO /
+  depth inputs.  Same kernels as the 3-D model; its 64-wide heads take the generic attention composition."""
+
+  def __init__(self, num_output_frames: int = 150, num_latent_tokens: int = 128, latent_token_dim: int = 64, num_frequencies: int = 32,
+               track_scale_factor: float = 1.0, time_scale_factor: float = 150.0, track_token_dim: int = 256,
+               encoder_latent_dim: int = 512, decoder_num_channels: int = 1024, decoder_scan_chunk_size: Optional[int] = None,
+               precision: str = 'bf16', workspace_fraction: float = 0.80):
+    super().__init__(num_output_frames=num_output_frames, num_latent_tokens=num_latent_tokens, latent_token_dim=latent_token_dim,
+                     num_frequencies=num_frequencies, track_scale_factor=track_scale_factor, time_scale_factor=time_scale_factor,
+                     track_token_dim=track_token_dim, encoder_latent_dim=encoder_latent_dim, decoder_num_channels=decoder_num_channels,
+                     dino_feature_dim=0, depth_feature_dim=0, use_dino=False, use_depth=False,
+                     decoder_scan_chunk_size=decoder_scan_chunk_size, precision=precision, workspace_fraction=workspace_fraction)
+    self._kind, self._nc = 1, 2
+    # transformer sizes of setup() (track_autoencoder.py:149-172)
+    self.num_heads, self.qkv_size = 8, 64 * 8
+    self.enc_mlp, self.enc_layers = 1024, 2
+    self.t2l_mlp, self.t2l_layers = 2048, 6
+    self.dec_mlp, self.dec_layers = 2048, 3
+    self.ro_mlp, self.ro_layers = 1024, 4
 
 
 PROF_CLASSES = ('gemm_nt_bf16 (tiled MFMA, Y=X.W / dX=dY.W^T)', 'gemm_tn_bf16 (tiled MFMA, dW=X^T.dY)', 'gemm_generic (strided MFMA)',

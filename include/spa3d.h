@@ -65,6 +65,10 @@ typedef struct {
   int32_t dec_mlp, dec_layers; /* 2048, 4 */
   int32_t ro_mlp, ro_layers;   /* 1536, 4 */
   int32_t precision;           /* SPA3D_F32 | SPA3D_BF16 */
+  int32_t model_kind;          /* 0 = TrackAutoEncoder3D (track_autoencoder_3d.py:43-357);
+                                  1 = the 2-D TRAJAN twin TrackAutoEncoder (track_autoencoder.py:117-390): 2 coordinates, no readout
+                                      token, visible-mean pooling, certainty head; dino/depth dims must be 0.  Tensors then carry 2
+                                      coordinates ([..,2] tracks, [B,Q,3] query points) */
 } spa3d_config;
 
 /* One batch: TrackAutoEncoder3DInputs (track_autoencoder_3d.py:23-40) + the loss targets

@@ -333,6 +333,87 @@ class TrackAutoEncoder3D:
 
 
 # --------------------------------------------------------------------------------------
+# the 2-D TRAJAN twin (track_autoencoder.py:117-390) -- runnable as written upstream, restated with the SAME blocks
+# --------------------------------------------------------------------------------------
+
+
+def config_2d(**kw) -> Config:
+  """hyper-parameters of TrackAutoEncoder (ta:120-135, 149-172)"""
+  base = dict(latent_token_dim=64, track_token_dim=256, encoder_latent_dim=512, decoder_num_channels=1024, use_dino=False,
+              use_depth=False, num_heads=8, qkv_size=512, enc_mlp=1024, enc_layers=2, t2l_mlp=2048, t2l_layers=6, dec_mlp=2048,
+              dec_layers=3, ro_mlp=1024, ro_layers=4)
+  base.update(kw)
+  return Config(**base)
+
+
+class TrackAutoEncoder2D(TrackAutoEncoder3D):
+  """track_autoencoder.TrackAutoEncoder: (x,y) tracks, key mask without a readout key, visible-mean pooling, certainty head."""
+
+  def embed_track_pos_visible(self, p, tracks, visible, dino_features=None, depth_features=None):  # ta:183-203
+    T = tracks.shape[-2]
+    fr_id = (torch.arange(T, dtype=torch.float32) / T).to(tracks.dtype)
+    fr_id = fr_id[None, None, :, None].expand(visible.shape)
+    return sinusoidal_embedding(torch.cat([tracks, fr_id], dim=-1) / self.cfg.track_scale_factor, self.cfg.num_frequencies)
+
+  def encode_tracks(self, p, tracks, visible, restart, dino_features=None, depth_features=None):  # ta:205-232
+    tok = dense(p['track_token_projection'], self.embed_track_pos_visible(p, tracks, visible))
+    B, N, T = tok.shape[:3]
+    partition = torch.arange(T)[None, None, :] < restart[:, None, None]
+    vis = visible[..., 0] != 0
+    km = partition & vis  # [B,N,T]; "ones_like(visible[..., newaxis]) * visible[..., newaxis, :]" is a key-only mask
+    tok = transformer(p['input_track_transformer'], tok, qq_mask=km[:, :, None, :].expand(B, N, T, T))
+    v = vis.to(tok.dtype)[..., None]
+    return (tok * v).sum(-2) / torch.clamp(v.sum(-2), min=1.0)
+
+  def get_decoder_context(self, inputs):  # ta:248-273
+    if 'query_points' in inputs:
+      decoder_query = inputs['query_points'][..., 1:]
+      query_frame = torch.round(inputs['query_points'][..., 0]).to(torch.int32)
+    else:
+      grid = torch.arange(32, dtype=torch.float32) / 32.0 + 1.0 / 64.0
+      qx, qy = torch.meshgrid(grid, grid, indexing='xy')
+      decoder_query = torch.stack([qx, qy], dim=-1).reshape(-1, 2)
+      lead = inputs['support_tracks'].shape[:-3]
+      decoder_query = decoder_query.expand(*lead, *decoder_query.shape).to(inputs['support_tracks'].dtype)
+      query_frame = torch.zeros(decoder_query.shape[:-1], dtype=torch.int32)
+    return DecoderContext(self.encode_point_identities(decoder_query), query_frame, inputs['boundary_frame'])
+
+  def decode(self, p, latents, ctx, discretize=True, noise=None):  # ta:290-350
+    r3 = super().decode(p, latents, ctx, discretize, noise)  # identical up to the head split; rebuild it from the raw head
+    T = self.cfg.num_output_frames
+    # super() stacked blocks 0,1,2 as coordinates and returned block 3 as visible logits; TRAJAN: blocks 0,1 coords, 2 visible, 3 certain
+    tracks = r3.tracks[..., :2]
+    visible_logits = r3.tracks[..., 2:3]
+    certain_logits = r3.visible_logits
+    return Results(tracks, visible_logits, certain_logits)
+
+
+def init_params_2d(cfg: Config, seed=0, dtype=torch.float32, perturb=0.0) -> Params:
+  p = init_params(cfg, seed=seed, dtype=dtype, with_dino=False, with_depth=False, perturb=perturb)
+  gen = torch.Generator().manual_seed(seed + 1000)
+  nf = cfg.num_frequencies
+  d, dd = cfg.track_token_dim, cfg.decoder_num_channels
+  del p['input_readout_token']  # declared in setup() but never called upstream -> no Flax parameter
+  p['track_token_projection'] = _dense_p(gen, 3 * 2 * nf, d, dtype)
+  p['query_encoder'] = _dense_p(gen, (2 * 2 * nf + 1) * 2 * nf, dd, dtype)
+  if perturb > 0:
+    for k in ('track_token_projection', 'query_encoder'):
+      p[k]['bias'] += perturb * torch.randn(p[k]['bias'].shape, generator=gen, dtype=torch.float64).to(dtype)
+  return p
+
+
+def synthetic_batch_2d(B, N, Q, T, seed=1234, dtype=torch.float32):
+  b = synthetic_batch(B, N, Q, T, seed=seed, dtype=dtype)
+  b['support_tracks'] = b['support_tracks'][..., :2].contiguous()
+  b['query_tracks'] = b['query_tracks'][..., :2].contiguous()
+  b['query_points'] = b['query_points'][..., :3].contiguous()
+  return b
+
+
+compute_loss_2d = None  # assigned below: same arithmetic as compute_loss_3d (train.py:60-93)
+
+
+# --------------------------------------------------------------------------------------
 # loss (train.py:96-129)
 # --------------------------------------------------------------------------------------
 
@@ -353,6 +434,9 @@ def compute_loss_3d(predictions: Results, targets, l1_weight=5000.0, bce_weight=
   pos = pos.sum() / denom
   vis = sigmoid_binary_cross_entropy(predictions.visible_logits, vm).sum() / denom
   return {'total_loss': l1_weight * pos + bce_weight * vis, 'position_loss': pos, 'visible_loss': vis}
+
+
+compute_loss_2d = compute_loss_3d  # train.py:60-93 is the same code on [B,Q,T,2]
 
 
 # --------------------------------------------------------------------------------------

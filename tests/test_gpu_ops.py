@@ -380,3 +380,41 @@ def test_linear_tiled_nt_a_stationary_two_teams(lib, monkeypatch, M, N, K, act, 
   monkeypatch.setenv('SPA3D_NT_ASTAT2', '2')
   monkeypatch.setenv('SPA3D_NT_256', '0')
   test_linear_tiled_nt(lib, M, N, K, act, res, bias)
+
+
+@pytest.mark.parametrize('dtype,impl', [(F32, 1), (BF16, 1), (BF16, 2)])
+def test_attention_fully_masked_sequence(lib, dtype, impl):
+  """where(mask, logit, finfo.min): a sequence with NO visible key attends uniformly (forward) and passes no gradient to
+  q/k through its logits (backward) -- generic and fused kernels."""
+  nseq, S, H, Dh = 3, 40, 8, 96
+  E = H * Dh
+  g = torch.Generator().manual_seed(31)
+  dt = _dt(dtype)
+  qkv = torch.randn(nseq, S, 3 * E, generator=g).to(dt)
+  sq = 1 + 0.2 * torch.randn(Dh, generator=g); sk = 1 + 0.2 * torch.randn(Dh, generator=g)
+  km = (torch.rand(nseq, S, generator=g) < 0.7).float(); km[:, 0] = 1.0
+  km[1] = 0.0  # fully masked sequence
+  d_o = torch.randn(nseq, S, E, generator=g).to(dt)
+  qkvd, sqd, skd, kmd, dod = qkv.cuda(), sq.cuda(), sk.cuda(), km.cuda(), d_o.cuda()
+  o = torch.empty(nseq, S, E, device='cuda', dtype=dt); lse = torch.zeros(nseq, H, S, 2, device='cuda')
+  ws = _ws(256 << 20)
+  assert lib.spa3d_op_attention(qkvd[..., :E].data_ptr(), qkvd[..., E:2 * E].data_ptr(), qkvd[..., 2 * E:].data_ptr(), 3 * E, 3 * E, 3 * E,
+                                sqd.data_ptr(), skd.data_ptr(), kmd.data_ptr(), nseq, S, S, H, Dh, o.data_ptr(), lse.data_ptr(), dtype, impl,
+                                ws.data_ptr(), ws.numel(), _s()) == 0
+  qr = qkv[..., :E].double().contiguous().requires_grad_(True)
+  kr = qkv[..., E:2 * E].double().contiguous().requires_grad_(True)
+  vr = qkv[..., 2 * E:].double().contiguous().requires_grad_(True)
+  ref = _attn_ref(qr, kr, vr, sq.double(), sk.double(), km, H, Dh)
+  ref.backward(d_o.double())
+  assert float(qr.grad[1].abs().max()) == 0.0 and float(kr.grad[1].abs().max()) == 0.0  # the oracle's own statement of the rule
+  dqkv = torch.full((nseq, S, 3 * E), float('nan'), device='cuda', dtype=dt)
+  dsq = torch.zeros(Dh, device='cuda'); dsk = torch.zeros(Dh, device='cuda')
+  assert lib.spa3d_op_attention_bwd(qkvd[..., :E].data_ptr(), qkvd[..., E:2 * E].data_ptr(), qkvd[..., 2 * E:].data_ptr(), 3 * E, 3 * E, 3 * E,
+                                    sqd.data_ptr(), skd.data_ptr(), kmd.data_ptr(), nseq, S, S, H, Dh, o.data_ptr(), lse.data_ptr(),
+                                    dod.data_ptr(), dqkv[..., :E].data_ptr(), dqkv[..., E:2 * E].data_ptr(), dqkv[..., 2 * E:].data_ptr(),
+                                    dsq.data_ptr(), dsk.data_ptr(), dtype, impl, ws.data_ptr(), ws.numel(), _s()) == 0
+  tol = 1e-4 if dtype == F32 else 3e-2
+  assert rel_err(o.float(), ref.detach()) < tol
+  assert float(dqkv[1, :, :2 * E].float().abs().max()) == 0.0
+  assert rel_err(dqkv[..., :E].float(), qr.grad) < tol and rel_err(dqkv[..., E:2 * E].float(), kr.grad) < tol
+  assert rel_err(dqkv[..., 2 * E:].float(), vr.grad) < tol
