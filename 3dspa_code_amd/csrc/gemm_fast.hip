@@ -831,6 +831,301 @@ static void launch_astat2(spa3d_ctx* c, const NtArgs& g) {
   gemm_nt_astat2_kernel<KT><<<(unsigned)g.tiles_m, 512, lds, c->stream>>>(g);
 }
 
+
+// =================================================================================================================
+// Ring kernel: persistent, 256x128x64 tile, 8 waves (4 x 2, 64x64 per wave), 3-slot LDS ring of (A 32 KiB | B 16 KiB).
+// Measurements on the simpler kernels say the NT GEMMs are LDS-DMA LATENCY bound (spreading the DMA issues later in a
+// K-step made them slower; deeper tiles or fewer bytes alone did not help): throughput ~ bytes in flight per CU / latency.
+// This kernel keeps TWO K-tiles (96 KiB) in flight per CU behind a counted `s_waitcnt vmcnt` + one raw `s_barrier` per
+// K-step, and the step sequence is flattened over all output tiles a workgroup owns (an M tile, then every N tile of
+// it), so the ring never drains at a tile boundary: the epilogue (registers -> global, bias from LDS) runs with the next
+// tile's operands already streaming.  One workgroup per CU, two waves per SIMD.
+// =================================================================================================================
+__global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(NtArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [3][A 32 KiB | B 16 KiB] | bias f32[N<=4096]
+  constexpr int SLOT = 49152;
+  float* const sbias = (float*)(smem + 3 * SLOT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sr = lane >> 3, scp = lane & 7;
+  const int sc = (scp ^ sr) * 8;
+  const int KT = g.K / 64;
+  const int G = gridDim.x;
+  const int my_m = (g.tiles_m - (int)blockIdx.x + G - 1) / G;  // tiles_m counts 256-row tiles here
+  const int nsteps = my_m * g.tiles_n * KT;
+  if (g.bias) for (int i = tid; i < g.N; i += 512) sbias[i] = g.bias[i];
+
+  // staging cursor (runs 2 steps ahead of the compute cursor)
+  int s_j = 0, s_tn = 0, s_kt = 0;
+  auto stage = [&](int slot) {
+    const int64_t tm = (int64_t)blockIdx.x + (int64_t)s_j * G;
+    char* sa = smem + slot * SLOT; char* sb = sa + 32768;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = w * 4 + i;
+      int64_t am = tm * 256 + piece * 8 + sr; if (am > g.M - 1) am = g.M - 1;
+      GLDS16(g.A + am * g.lda + sc + s_kt * 64, sa + piece * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = w * 2 + i;
+      int bn = s_tn * 128 + piece * 8 + sr; if (bn > g.N - 1) bn = g.N - 1;
+      GLDS16(g.Bt + (int64_t)bn * g.ldb + sc + s_kt * 64, sb + piece * 1024);
+    }
+    if (++s_kt == KT) { s_kt = 0; if (++s_tn == g.tiles_n) { s_tn = 0; ++s_j; } }
+  };
+  if (nsteps > 0) stage(0);
+  if (nsteps > 1) stage(1);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int a_off = (wm + fr) * 128, b_off = (wn + fr) * 128;
+  const int x0 = ((fq) ^ (fr & 7)) * 16, x1 = ((4 + fq) ^ (fr & 7)) * 16;
+  // stores of an epilogue sit between the weight tiles in vmcnt's in-order count; when their number is known exactly
+  // (interior tile, no load in the epilogue) it is added to the allowance so the ring does not wait for them
+  const bool count_stores = !g.aux && !g.accumulate && (g.N % 128 == 0);
+  const int nstore = g.pre_out ? 32 : 16;
+
+  int c_j = 0, c_tn = 0, c_kt = 0, since_epi = 1000;
+  for (int step = 0; step < nsteps; ++step) {
+    // tile `step` has landed once only the younger tile step+1 (6 LDS-DMA per wave) [+ counted stores] is outstanding
+    if (step + 1 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (since_epi < 2 && nstore == 16) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+    else if (since_epi < 2 && nstore == 32) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (step + 2 < nsteps) stage((step + 2) % 3);  // slot of step-1: every wave has left it
+    ++since_epi;
+    const char* sa = smem + (step % 3) * SLOT;
+    const char* sb = sa + 32768;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int xo = ks ? x1 : x0;
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(sa + a_off + i * 2048 + xo);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(sb + b_off + j * 2048 + xo);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (++c_kt == KT) {
+      const int64_t m0 = ((int64_t)blockIdx.x + (int64_t)c_j * G) * 256;
+      const int n0 = c_tn * 128;
+      const bool interior = m0 + 256 <= g.M;
+      since_epi = (count_stores && interior) ? 0 : 1000;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t gm = m0 + wm + i * 16 + fr;
+        int64_t crow = gm;
+        if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int gn = n0 + wn + j * 16 + fq * 4;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] = g.alpha * acc[i][j][r]; acc[i][j][r] = 0.f; }
+          if (gm >= g.M || gn >= g.N) continue;
+          if (g.bias) { const f32x4 b4 = *(const f32x4*)(sbias + gn); v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3]; }
+          const int64_t ci = crow * g.ldc + gn;
+          if (g.pre_out) { u16x4 p4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p4[r] = f2bf(v[r]);
+            *(u16x4*)(g.pre_out + ci) = p4; }
+          if (g.epi == EPI_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+          }
+          if (g.aux) {
+            const u16x4 x4 = *(const u16x4*)(g.aux + ci);
+            if (g.epi == EPI_MUL_GELU_GRAD) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bf2f(x4[r]);
+            }
+          }
+          if (g.out_f32) {
+            float4* cp = (float4*)((float*)g.C + ci);
+            if (g.accumulate) { const float4 o = *cp; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+            *cp = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            u16x4* cp = (u16x4*)((bf16_t*)g.C + ci);
+            if (g.accumulate) { const u16x4 o = *cp;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bf2f(o[r]); }
+            u16x4 o4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o4[r] = f2bf(v[r]);
+            *cp = o4;
+          }
+        }
+      }
+      c_kt = 0; if (++c_tn == g.tiles_n) { c_tn = 0; ++c_j; }
+    }
+  }
+}
+
+
+// =================================================================================================================
+// Ping-pong kernel: the ring kernel's data path (persistent, 256x128x64 tile, 3-slot ring, counted vmcnt, steps
+// flattened over output tiles) with the schedule of cdna_hip_programming.md's 8-phase template in its smallest form:
+// every K-step of a wave is  [LOAD: 16 ds_read_b128 of the step's fragments + 6 LDS-DMA for the tile two steps ahead]
+// s_barrier [MFMA: 32 MFMAs from registers] s_barrier,  and the two 4-wave teams (rows 0-127 / 128-255 of the tile)
+// run ONE BARRIER APART, so on every SIMD one wave is in its MFMA section while its partner is in its LOAD section.
+// Hazards (global barrier index b; team 0's LOAD(s) is interval (2s,2s+1), team 1's is (2s+1,2s+2)):
+//   RAW  every wave confirms its pieces of tile s (vmcnt) before barrier 2s: team 0 just before it, team 1 at the end of
+//        its LOAD(s-1);
+//   WAR  tile s+2 reuses the slot of tile s-1, last read in interval (2s-1,2s); it is issued after barrier 2s.
+// =================================================================================================================
+__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NtArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [3][A 32 KiB | B 16 KiB] | bias f32[N<=4096]
+  constexpr int SLOT = 49152;
+  float* const sbias = (float*)(smem + 3 * SLOT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = w >> 2, tw = w & 3;
+  const int wm = team * 128 + (tw >> 1) * 64, wn = (tw & 1) * 64;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sr = lane >> 3, scp = lane & 7;
+  const int sc = (scp ^ sr) * 8;
+  const int KT = g.K / 64;
+  const int G = gridDim.x;
+  const int my_m = (g.tiles_m - (int)blockIdx.x + G - 1) / G;
+  const int nsteps = my_m * g.tiles_n * KT;
+  if (g.bias) for (int i = tid; i < g.N; i += 512) sbias[i] = g.bias[i];
+
+  int s_j = 0, s_tn = 0, s_kt = 0;
+  auto stage = [&](int slot) {
+    const int64_t tm = (int64_t)blockIdx.x + (int64_t)s_j * G;
+    char* sa = smem + slot * SLOT; char* sb = sa + 32768;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = w * 4 + i;
+      int64_t am = tm * 256 + piece * 8 + sr; if (am > g.M - 1) am = g.M - 1;
+      GLDS16(g.A + am * g.lda + sc + s_kt * 64, sa + piece * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = w * 2 + i;
+      int bn = s_tn * 128 + piece * 8 + sr; if (bn > g.N - 1) bn = g.N - 1;
+      GLDS16(g.Bt + (int64_t)bn * g.ldb + sc + s_kt * 64, sb + piece * 1024);
+    }
+    if (++s_kt == KT) { s_kt = 0; if (++s_tn == g.tiles_n) { s_tn = 0; ++s_j; } }
+  };
+  // own pieces of a tile have landed when only the ONE younger tile (6 LDS-DMA of this wave) may still be outstanding
+  auto confirm = [&](bool younger_tile_issued) {
+    if (younger_tile_issued) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  if (nsteps > 0) stage(0);
+  if (nsteps > 1) stage(1);
+  __syncthreads();  // bias visible (also drains the two staged tiles once; start-up only)
+  if (team == 1) __builtin_amdgcn_s_barrier();  // the stagger: team 1 runs one barrier behind
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int a_off = (wm + fr) * 128, b_off = (wn + fr) * 128;
+  const int x0 = ((fq) ^ (fr & 7)) * 16, x1 = ((4 + fq) ^ (fr & 7)) * 16;
+
+  int c_j = 0, c_tn = 0, c_kt = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    if (team == 0) confirm(step + 1 < nsteps);      // tile `step`: before global barrier 2*step
+    __builtin_amdgcn_s_barrier();
+    // ---------------- LOAD section
+    const char* sa = smem + (step % 3) * SLOT;
+    const char* sb = sa + 32768;
+    bf16x8 af[2][4], bfr[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int xo = ks ? x1 : x0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[ks][i] = *(const bf16x8*)(sa + a_off + i * 2048 + xo);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[ks][j] = *(const bf16x8*)(sb + b_off + j * 2048 + xo);
+    }
+    if (step + 2 < nsteps) stage((step + 2) % 3);
+    if (team == 1 && step + 1 < nsteps) confirm(step + 2 < nsteps);  // tile step+1: before global barrier 2*(step+1)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // fragments are in registers: the slot may be refilled later
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---------------- MFMA section (registers only)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    if (++c_kt == KT) {
+      const int64_t m0 = ((int64_t)blockIdx.x + (int64_t)c_j * G) * 256;
+      const int n0 = c_tn * 128;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t gm = m0 + wm + i * 16 + fr;
+        int64_t crow = gm;
+        if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int gn = n0 + wn + j * 16 + fq * 4;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] = g.alpha * acc[i][j][r]; acc[i][j][r] = 0.f; }
+          if (gm >= g.M || gn >= g.N) continue;
+          if (g.bias) { const f32x4 b4 = *(const f32x4*)(sbias + gn); v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3]; }
+          const int64_t ci = crow * g.ldc + gn;
+          if (g.pre_out) { u16x4 p4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p4[r] = f2bf(v[r]);
+            *(u16x4*)(g.pre_out + ci) = p4; }
+          if (g.epi == EPI_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+          }
+          if (g.aux) {
+            const u16x4 x4 = *(const u16x4*)(g.aux + ci);
+            if (g.epi == EPI_MUL_GELU_GRAD) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bf2f(x4[r]);
+            }
+          }
+          if (g.out_f32) {
+            float4* cp = (float4*)((float*)g.C + ci);
+            if (g.accumulate) { const float4 o = *cp; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+            *cp = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            u16x4* cp = (u16x4*)((bf16_t*)g.C + ci);
+            if (g.accumulate) { const u16x4 o = *cp;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bf2f(o[r]); }
+            u16x4 o4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o4[r] = f2bf(v[r]);
+            *cp = o4;
+          }
+        }
+      }
+      c_kt = 0; if (++c_tn == g.tiles_n) { c_tn = 0; ++c_j; }
+    }
+  }
+  if (team == 0) __builtin_amdgcn_s_barrier();  // matches team 1's extra barrier
+}
+
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
@@ -858,6 +1153,17 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
   ProfScope ps(c, PROF_GEMM_NT, 2.0 * (double)d.M * d.N * d.K, ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * 2.0);
   const int KT = d.K / 64;
+  if (c->nt_ring && d.N % 128 == 0 && d.N <= 4096 && (d.M >= 256 * 512 || c->nt_ring == 2 || c->nt_ring == 4)) {
+    NtArgs g2 = g; g2.tiles_m = (int)((d.M + 255) / 256); g2.tiles_n = d.N / 128;
+    static bool attr4 = false;
+    if (!attr4) { (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); attr4 = true; }
+    static bool attr5 = false;
+    if (!attr5) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); attr5 = true; }
+    if (c->nt_ring >= 3) gemm_nt_ring_kernel<<<(unsigned)std::min(256, g2.tiles_m), 512, 163840, c->stream>>>(g2);
+    else gemm_nt_pp_kernel<<<(unsigned)std::min(256, g2.tiles_m), 512, 163840, c->stream>>>(g2);
+    SPA_LAUNCH_CHECK(c);
+    return true;
+  }
   // 256x256 tile (128 FLOP per staged byte): measured +3..4 % over 128x128 at K >= 1280 (850 vs 821, 917 vs 882 TF/s), equal at
   // K = 768, and much slower at K = 384 (433 vs 667: one workgroup per CU cannot hide a 6-step tile's prologue/epilogue)
   if (c->nt_256 && d.N % 256 == 0 && ((d.M >= 256 * 64 && KT >= 16) || c->nt_256 == 2)) {
