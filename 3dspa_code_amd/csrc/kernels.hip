@@ -1005,280 +1005,272 @@ INST(bf16_t)
 // ---------------------------------------------------------------------------------------------
 // Single-query attention (last block of the track encoder / readout stack: only token 0 leaves the stack,
 // track_autoencoder_3d.py:187-188,286, so only its query row is needed; K/V still come from every token).
-// One wave per (sequence, head).  lane = 4*kgrp + part: 16 keys per pass, each key row split over 4 lanes
-// (Dh/4 contiguous channels each).  RMSNorm of q/k, 1/sqrt(Dh), key mask, softmax and PV fused; the
-// probabilities are kept (fp32, tiny) for the backward.
+// One wave per (sequence, head).  lane = 4*kgrp + part: 16 keys per pass, each key row split over 4 lanes.
+// RMSNorm of q/k, 1/sqrt(Dh), key mask, softmax and PV fused; the probabilities are kept (fp32, tiny) for the
+// backward.  HBM-bound (K and V are read once): scores live in LDS and the key loop is a runtime loop so the kernels
+// stay near 100 VGPRs (the first version unrolled 20 passes over 32-wide arrays: 256 VGPRs, one wave per SIMD, spills).
+// CC = channels per lane (Dh/4) at compile time; vec: 16-byte accesses with 16-byte chunk i of a lane = chunk 4*i+part
+// of the row, so the 4 lanes of a key touch 64 contiguous bytes per instruction.
 // ---------------------------------------------------------------------------------------------
-#define Q1_MAXIT 20   // S <= 320
-#define Q1_MAXC 32    // Dh/4 <= 32
-// contiguous C-channel part of a row -> f[0..C): 16-byte loads when C and the address allow, else element-wise
-// Channel map of a lane's Dh/4 values.  Vector path: 16-byte chunk i of the lane is chunk 4*i + part of the row, so the 4
-// lanes of a key read 64 contiguous bytes per instruction (3 instructions cover a 192-byte row).  Scalar path: contiguous.
-template <typename T>
-__device__ __forceinline__ int q1_chan(int j, int part, int C, bool vec) {
+#define Q1_MAXS 320
+template <typename T, int CC>
+__device__ __forceinline__ int q1_chan(int j, int part, bool vec) {
   constexpr int NV = VecOf<T>::N;
-  return vec ? (j / NV) * (4 * NV) + part * NV + (j % NV) : part * C + j;
+  return vec ? (j / NV) * (4 * NV) + part * NV + (j % NV) : part * CC + j;
 }
-// `p` points at channel 0 of the row (head offset applied); f[j] <-> channel q1_chan(j)
-template <typename T>
-__device__ __forceinline__ void q1_load(const T* p, int C, bool vec, float (&f)[Q1_MAXC], int part) {
+template <typename T, int CC>
+__device__ __forceinline__ void q1_load(const T* p, bool vec, float (&f)[CC], int part) {
   constexpr int NV = VecOf<T>::N;
   if (vec) {
 #pragma unroll
-    for (int i = 0; i < Q1_MAXC / NV; ++i)
-      if (i * NV < C) {
-        float t[NV]; load_vec<T, NV>(p + (4 * i + part) * NV, t);
+    for (int i = 0; i < CC / NV; ++i) {
+      float t[NV]; load_vec<T, NV>(p + (4 * i + part) * NV, t);
 #pragma unroll
-        for (int j = 0; j < NV; ++j) f[i * NV + j] = t[j];
-      }
+      for (int j = 0; j < NV; ++j) f[i * NV + j] = t[j];
+    }
   } else {
 #pragma unroll
-    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) f[j] = ld(p + part * C + j);
+    for (int j = 0; j < CC; ++j) f[j] = ld(p + part * CC + j);
   }
 }
-template <typename T>
-__device__ __forceinline__ void q1_store(T* p, int C, bool vec, const float (&f)[Q1_MAXC], int part) {
+template <typename T, int CC>
+__device__ __forceinline__ void q1_store(T* p, bool vec, const float (&f)[CC], int part) {
   constexpr int NV = VecOf<T>::N;
   if (vec) {
 #pragma unroll
-    for (int i = 0; i < Q1_MAXC / NV; ++i)
-      if (i * NV < C) {
-        float t[NV];
+    for (int i = 0; i < CC / NV; ++i) {
+      float t[NV];
 #pragma unroll
-        for (int j = 0; j < NV; ++j) t[j] = f[i * NV + j];
-        store_vec<T, NV>(p + (4 * i + part) * NV, t);
-      }
+      for (int j = 0; j < NV; ++j) t[j] = f[i * NV + j];
+      store_vec<T, NV>(p + (4 * i + part) * NV, t);
+    }
   } else {
 #pragma unroll
-    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) st(p + part * C + j, f[j]);
+    for (int j = 0; j < CC; ++j) st(p + part * CC + j, f[j]);
   }
 }
-template <typename T>
+__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); return v; }
+__device__ __forceinline__ float kgrp_sum(float v) {
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int CC>
 __global__ __launch_bounds__(256) void attn_q1_fwd_kernel(const T* __restrict__ q0, int64_t ldq0, const T* __restrict__ k, const T* __restrict__ v,
                                                           int64_t ldk, int64_t ldv, const float* __restrict__ sq, const float* __restrict__ sk,
-                                                          const float* __restrict__ km, int64_t nprob, int S, int H, int Dh,
-                                                          T* __restrict__ o0, float* __restrict__ p0, int vec_) {
-  const int lane = threadIdx.x & 63, part = lane & 3, kg = lane >> 2;
-  const int C = Dh / 4;
+                                                          const float* __restrict__ km, int64_t nprob, int S, int H, T* __restrict__ o0,
+                                                          float* __restrict__ p0, int vec_) {
+  __shared__ float scs[4][Q1_MAXS];
+  constexpr int Dh = CC * 4;
+  const int lane = threadIdx.x & 63, part = lane & 3, kg = lane >> 2, wv = threadIdx.x >> 6;
   const bool vec = vec_ != 0;
-  float sqv[Q1_MAXC], skv[Q1_MAXC];
-#pragma unroll
-  for (int j = 0; j < Q1_MAXC; ++j) if (j < C) { const int ch = q1_chan<T>(j, part, C, vec); sqv[j] = sq[ch]; skv[j] = sk[ch]; }
+  float* sc = scs[wv];
   const float alpha = rsqrtf((float)Dh);
   const int nit = (S + 15) / 16;
-  for (int64_t prob = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); prob < nprob; prob += (int64_t)gridDim.x * 4) {
+  float sqv[CC], skv[CC];
+#pragma unroll
+  for (int j = 0; j < CC; ++j) { const int ch = q1_chan<T, CC>(j, part, vec); sqv[j] = sq[ch]; skv[j] = sk[ch]; }
+  for (int64_t prob = (int64_t)blockIdx.x * 4 + wv; prob < nprob; prob += (int64_t)gridDim.x * 4) {
     const int64_t seq = prob / H; const int h = (int)(prob - seq * H);
-    float qh[Q1_MAXC]; float ss = 0.f;
-    q1_load<T>(q0 + seq * ldq0 + h * Dh, C, vec, qh, part);
+    float qh[CC];
+    q1_load<T, CC>(q0 + seq * ldq0 + h * Dh, vec, qh, part);
+    float ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) ss += qh[j] * qh[j];
-    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64);
-    const float rq = rsqrtf(ss / Dh + 1e-6f);
+    for (int j = 0; j < CC; ++j) ss += qh[j] * qh[j];
+    const float rq = rsqrtf(quad_sum(ss) / Dh + 1e-6f);
 #pragma unroll
-    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) qh[j] *= rq * sqv[j];
-    float sc[Q1_MAXIT]; float m = -3.4028234663852886e38f;
+    for (int j = 0; j < CC; ++j) qh[j] *= rq * sqv[j];
+    float m = -3.4028234663852886e38f;
+#pragma unroll 2
+    for (int it = 0; it < nit; ++it) {
+      const int key = it * 16 + kg;
+      const int kr_ = key < S ? key : S - 1;  // absent keys re-read the last row (keeps the quad shuffles convergent), result unused
+      float kv_[CC];
+      q1_load<T, CC>(k + (seq * S + kr_) * ldk + h * Dh, vec, kv_, part);
+      float ks = 0.f, d = 0.f;
 #pragma unroll
-    for (int it = 0; it < Q1_MAXIT; ++it) {
-      sc[it] = -__builtin_inff();
-      if (it < nit) {
-        const int key = it * 16 + kg;
-        if (key < S) {
-          const T* kr = k + (seq * S + key) * ldk + h * Dh;
-          float kv_[Q1_MAXC]; float ks = 0.f;
-          q1_load<T>(kr, C, vec, kv_, part);
-#pragma unroll
-          for (int j = 0; j < Q1_MAXC; ++j) if (j < C) ks += kv_[j] * kv_[j];
-          ks += __shfl_xor(ks, 1, 64); ks += __shfl_xor(ks, 2, 64);
-          const float rk = rsqrtf(ks / Dh + 1e-6f);
-          float d = 0.f;
-#pragma unroll
-          for (int j = 0; j < Q1_MAXC; ++j) if (j < C) d += qh[j] * kv_[j] * rk * skv[j];
-          d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64);
-          float lg = d * alpha;
-          if (km && km[seq * S + key] == 0.f) lg = -3.4028234663852886e38f;
-          sc[it] = lg; m = fmaxf(m, lg);
-        } else {  // keep the 4-lane shuffles convergent for absent keys
-          float z = 0.f; z += __shfl_xor(z, 1, 64); z += __shfl_xor(z, 2, 64); z += __shfl_xor(z, 1, 64); z += __shfl_xor(z, 2, 64);
-        }
-      }
+      for (int j = 0; j < CC; ++j) { ks += kv_[j] * kv_[j]; d += qh[j] * kv_[j] * skv[j]; }
+      ks = quad_sum(ks); d = quad_sum(d);
+      float lg = d * rsqrtf(ks / Dh + 1e-6f) * alpha;
+      if (km && km[seq * S + kr_] == 0.f) lg = -3.4028234663852886e38f;
+      if (key < S) { m = fmaxf(m, lg); if (part == 0) sc[key] = lg; }
     }
 #pragma unroll
     for (int o = 4; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     float l = 0.f;
-#pragma unroll
-    for (int it = 0; it < Q1_MAXIT; ++it) if (it < nit) { sc[it] = expf(sc[it] - m); l += sc[it]; }
-#pragma unroll
-    for (int o = 4; o < 64; o <<= 1) l += __shfl_xor(l, o, 64);
+    for (int key = lane; key < S; key += 64) { const float e = expf(sc[key] - m); sc[key] = e; l += e; }  // own-wave LDS, program order
+    l = wave_sum(l);
     const float inv = 1.f / l;
-    float acc[Q1_MAXC];
+    float acc[CC];
 #pragma unroll
-    for (int j = 0; j < Q1_MAXC; ++j) acc[j] = 0.f;
+    for (int j = 0; j < CC; ++j) acc[j] = 0.f;
+#pragma unroll 2
+    for (int it = 0; it < nit; ++it) {
+      const int key = it * 16 + kg;
+      if (key < S) {
+        const float p = sc[key] * inv;
+        if (part == 0) p0[prob * S + key] = p;
+        float vv[CC];
+        q1_load<T, CC>(v + (seq * S + key) * ldv + h * Dh, vec, vv, part);
 #pragma unroll
-    for (int it = 0; it < Q1_MAXIT; ++it)
-      if (it < nit) {
-        const int key = it * 16 + kg;
-        if (key < S) {
-          const float p = sc[it] * inv;
-          if (part == 0) p0[prob * S + key] = p;
-          const T* vr = v + (seq * S + key) * ldv + h * Dh;
-          float vv[Q1_MAXC];
-          q1_load<T>(vr, C, vec, vv, part);
-#pragma unroll
-          for (int j = 0; j < Q1_MAXC; ++j) if (j < C) acc[j] += p * vv[j];
-        }
+        for (int j = 0; j < CC; ++j) acc[j] += p * vv[j];
       }
+    }
 #pragma unroll
-    for (int j = 0; j < Q1_MAXC; ++j)
-      if (j < C) {
-#pragma unroll
-        for (int o = 4; o < 64; o <<= 1) acc[j] += __shfl_xor(acc[j], o, 64);
-      }
-    if (kg == 0) q1_store<T>(o0 + seq * (int64_t)H * Dh + h * Dh, C, vec, acc, part);
+    for (int j = 0; j < CC; ++j) acc[j] = kgrp_sum(acc[j]);
+    if (kg == 0) q1_store<T, CC>(o0 + seq * (int64_t)H * Dh + h * Dh, vec, acc, part);
   }
 }
 template <typename T>
 void k_attn_q1_fwd(spa3d_ctx* c, const T* q0, int64_t ldq0, const T* k, const T* v, int64_t ldk, int64_t ldv, const float* sq, const float* sk,
                    const float* km, int64_t nseq, int S, int H, int Dh, T* o0, float* p0) {
   if (c->dry || nseq == 0) return;
+  if (S > Q1_MAXS || Dh % 4 || Dh > 128) { if (!c->hip_err) { c->hip_err = -3; c->err = "attn_q1: S <= 320 and Dh % 4 == 0, Dh <= 128 required"; } return; }
   const int64_t nprob = nseq * H;
   unsigned g = (unsigned)std::min<int64_t>(cdiv(nprob, 4), 8192);
   constexpr int NV = VecOf<T>::N;
   const int vec = (Dh % (4 * NV) == 0 && ldk % NV == 0 && ldv % NV == 0 && ldq0 % NV == 0 &&
                    ((((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)q0) | ((uintptr_t)o0)) & 15) == 0) ? 1 : 0;
-  attn_q1_fwd_kernel<T><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, Dh, o0, p0, vec);
+#define Q1F(CCv) attn_q1_fwd_kernel<T, CCv><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, o0, p0, vec)
+  switch (Dh / 4) { case 24: Q1F(24); break; case 16: Q1F(16); break; case 32: Q1F(32); break; case 8: Q1F(8); break; case 4: Q1F(4); break;
+    case 2: Q1F(2); break; default: if (!c->hip_err) { c->hip_err = -3; c->err = "attn_q1: unsupported head width"; } return; }
+#undef Q1F
   SPA_LAUNCH_CHECK(c);
 }
 
 // backward of the above: dq0 [nseq, H*Dh]; dk, dv for EVERY key row (overwritten); scale gradients accumulated.
-template <typename T>
+// With x^ the RMS-normalised rows, q^ = x^_q*s_q, k^ = x^_k*s_k and ds_k = p_k (dp_k - sum p dp) / sqrt(Dh):
+//   u = sum_k ds_k x^_k  gives both  dq^ = u*s_k  and  ds_k(scale) = q^*u;   dk^_k = ds_k q^;  dv_k = p_k dO.
+// Registers: q^, dO, u (+ one key row); the scales and the scale-gradient accumulators live in LDS.
+template <typename T, int CC>
 __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ q0, int64_t ldq0, const T* __restrict__ k, const T* __restrict__ v,
                                                           int64_t ldk, int64_t ldv, const float* __restrict__ sq, const float* __restrict__ sk,
-                                                          const float* __restrict__ km, int64_t nprob, int S, int H, int Dh,
+                                                          const float* __restrict__ km, int64_t nprob, int S, int H,
                                                           const float* __restrict__ p0, const T* __restrict__ d_o0, T* __restrict__ dq0,
                                                           T* __restrict__ dk, T* __restrict__ dv, float* __restrict__ dsq, float* __restrict__ dsk,
                                                           int vec_) {
-  __shared__ float red[2][4 * Q1_MAXC];
-  const int lane = threadIdx.x & 63, part = lane & 3, kg = lane >> 2;
-  const int C = Dh / 4;
+  __shared__ float dps[4][Q1_MAXS];
+  __shared__ float scl[2][4 * CC];  // s_q, s_k in lane-channel order [part][j]
+  __shared__ float red[2][4 * CC];  // block accumulators of d s_q, d s_k
+  constexpr int Dh = CC * 4;
+  constexpr int NV = VecOf<T>::N;
+  constexpr int G = (CC % NV == 0) ? NV : 1;  // output chunk; vec implies G == NV
+  const int lane = threadIdx.x & 63, part = lane & 3, kg = lane >> 2, wv = threadIdx.x >> 6;
   const bool vec = vec_ != 0;
-  float sqv[Q1_MAXC], skv[Q1_MAXC];
-#pragma unroll
-  for (int j = 0; j < Q1_MAXC; ++j) if (j < C) { const int ch = q1_chan<T>(j, part, C, vec); sqv[j] = sq[ch]; skv[j] = sk[ch]; }
+  float* dp = dps[wv];
+  const float* sql = scl[0] + part * CC;
+  const float* skl = scl[1] + part * CC;
   const float alpha = rsqrtf((float)Dh);
   const int nit = (S + 15) / 16;
-  float dsq_acc[Q1_MAXC], dsk_acc[Q1_MAXC];
-#pragma unroll
-  for (int j = 0; j < Q1_MAXC; ++j) { dsq_acc[j] = 0.f; dsk_acc[j] = 0.f; }
-  for (int64_t prob = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); prob < nprob; prob += (int64_t)gridDim.x * 4) {
+  for (int t = threadIdx.x; t < 4 * CC; t += 256) {
+    const int pt = t / CC, j = t - pt * CC;
+    const int ch = q1_chan<T, CC>(j, pt, vec);
+    scl[0][t] = sq[ch]; scl[1][t] = sk[ch]; red[0][t] = 0.f; red[1][t] = 0.f;
+  }
+  __syncthreads();
+  for (int64_t prob = (int64_t)blockIdx.x * 4 + wv; prob < nprob; prob += (int64_t)gridDim.x * 4) {
     const int64_t seq = prob / H; const int h = (int)(prob - seq * H);
-    float xq[Q1_MAXC], qh[Q1_MAXC], dout[Q1_MAXC]; float ss = 0.f;
-    q1_load<T>(q0 + seq * ldq0 + h * Dh, C, vec, xq, part);
-    q1_load<T>(d_o0 + seq * (int64_t)H * Dh + h * Dh, C, vec, dout, part);
+    float qs[CC], dout[CC];
+    q1_load<T, CC>(q0 + seq * ldq0 + h * Dh, vec, qs, part);
+    q1_load<T, CC>(d_o0 + seq * (int64_t)H * Dh + h * Dh, vec, dout, part);
+    float ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) ss += xq[j] * xq[j];
-    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64);
-    const float rq = rsqrtf(ss / Dh + 1e-6f);
+    for (int j = 0; j < CC; ++j) ss += qs[j] * qs[j];
+    const float rq = rsqrtf(quad_sum(ss) / Dh + 1e-6f);
 #pragma unroll
-    for (int j = 0; j < Q1_MAXC; ++j) if (j < C) { xq[j] *= rq; qh[j] = xq[j] * sqv[j]; }
-    // pass 1: dp_k = dO . V_k ; sum_k p_k dp_k
-    float dp[Q1_MAXIT]; float pd = 0.f;
+    for (int j = 0; j < CC; ++j) qs[j] *= rq * sql[j];  // q^
+    // pass 1: dp_k = dO . V_k (to LDS) and sum_k p_k dp_k
+    float pd = 0.f;
+#pragma unroll 2
+    for (int it = 0; it < nit; ++it) {
+      const int key = it * 16 + kg;
+      const int kr_ = key < S ? key : S - 1;
+      float vv[CC];
+      q1_load<T, CC>(v + (seq * S + kr_) * ldv + h * Dh, vec, vv, part);
+      float d = 0.f;
 #pragma unroll
-    for (int it = 0; it < Q1_MAXIT; ++it) {
-      dp[it] = 0.f;
-      if (it < nit) {
-        const int key = it * 16 + kg;
-        float d = 0.f;
-        if (key < S) {
-          const T* vr = v + (seq * S + key) * ldv + h * Dh;
-          float vv[Q1_MAXC];
-          q1_load<T>(vr, C, vec, vv, part);
+      for (int j = 0; j < CC; ++j) d += dout[j] * vv[j];
+      d = quad_sum(d);
+      if (key < S && part == 0) { dp[key] = d; pd += p0[prob * S + key] * d; }
+    }
+    pd = wave_sum(pd);
+    // pass 2: per key dv, dk (through the RMSNorm) and u
+    float u[CC];
 #pragma unroll
-          for (int j = 0; j < Q1_MAXC; ++j) if (j < C) d += dout[j] * vv[j];
+    for (int j = 0; j < CC; ++j) u[j] = 0.f;
+    for (int it = 0; it < nit; ++it) {
+      const int key = it * 16 + kg;
+      const bool valid = key < S;
+      const int kr_ = valid ? key : S - 1;
+      const int64_t roff = seq * S + kr_;
+      float xk[CC];
+      q1_load<T, CC>(k + roff * ldk + h * Dh, vec, xk, part);
+      float ks = 0.f;
+#pragma unroll
+      for (int j = 0; j < CC; ++j) ks += xk[j] * xk[j];
+      const float rk = rsqrtf(quad_sum(ks) / Dh + 1e-6f);
+      const float p = valid ? p0[prob * S + kr_] : 0.f;
+      const bool keep = !(km && km[seq * S + kr_] == 0.f);
+      const float ds = (valid && keep) ? p * (dp[kr_] - pd) * alpha : 0.f;  // where() passes no gradient to masked logits
+      float gx = 0.f;
+#pragma unroll
+      for (int j = 0; j < CC; ++j) {
+        xk[j] *= rk;                          // x^ of the key row
+        u[j] += ds * xk[j];
+        gx += qs[j] * skl[j] * xk[j];         // (dk^ * s_k) . x^ / ds
+      }
+      gx = quad_sum(gx) * ds / Dh;
+      if (valid) {
+        T* dkr = dk + roff * ldk + h * Dh;
+        T* dvr = dv + roff * ldv + h * Dh;
+#pragma unroll
+        for (int i = 0; i < CC / G; ++i) {
+          float ok[G], ov[G];
+#pragma unroll
+          for (int jj = 0; jj < G; ++jj) {
+            const int j = i * G + jj;
+            ok[jj] = rk * (ds * qs[j] * skl[j] - xk[j] * gx);
+            ov[jj] = p * dout[j];
+          }
+          if (vec) {
+            store_vec<T, G>(dkr + (4 * i + part) * G, ok);
+            store_vec<T, G>(dvr + (4 * i + part) * G, ov);
+          } else {
+#pragma unroll
+            for (int jj = 0; jj < G; ++jj) { st(dkr + part * CC + i * G + jj, ok[jj]); st(dvr + part * CC + i * G + jj, ov[jj]); }
+          }
         }
-        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64);
-        dp[it] = d;
-        if (key < S && part == 0) pd += p0[prob * S + key] * d;
       }
     }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) pd += __shfl_xor(pd, o, 64);
-    // pass 2: per key dv, dk (through the RMSNorm), and the dq^ accumulation
-    float dqh[Q1_MAXC];
-#pragma unroll
-    for (int j = 0; j < Q1_MAXC; ++j) dqh[j] = 0.f;
-#pragma unroll
-    for (int it = 0; it < Q1_MAXIT; ++it)
-      if (it < nit) {
-        const int key = it * 16 + kg;
-        const bool valid = key < S;
-        float xk[Q1_MAXC]; float ks = 0.f, p = 0.f; bool keep = true;
-        const int64_t roff = valid ? (seq * S + key) : (seq * S);
-        if (valid) { p = p0[prob * S + key]; keep = !(km && km[seq * S + key] == 0.f); }
-        q1_load<T>(k + roff * ldk + h * Dh, C, vec, xk, part);
-#pragma unroll
-        for (int j = 0; j < Q1_MAXC; ++j) if (j < C) ks += xk[j] * xk[j];
-        ks += __shfl_xor(ks, 1, 64); ks += __shfl_xor(ks, 2, 64);
-        const float rk = rsqrtf(ks / Dh + 1e-6f);
-        const float ds = keep ? p * (dp[it] - pd) * alpha : 0.f;  // where() passes no gradient to masked logits
-        float gx = 0.f;
-#pragma unroll
-        for (int j = 0; j < Q1_MAXC; ++j)
-          if (j < C) {
-            xk[j] *= rk;                                  // x^ of the key row
-            dqh[j] += ds * xk[j] * skv[j];                // dq^ += ds * k^
-            gx += ds * qh[j] * skv[j] * xk[j];            // g = dk^ * s_k ; dk^ = ds * q^
-          }
-        gx += __shfl_xor(gx, 1, 64); gx += __shfl_xor(gx, 2, 64);
-        gx /= Dh;
-        if (valid) {
-          float ok[Q1_MAXC], ov[Q1_MAXC];
-#pragma unroll
-          for (int j = 0; j < Q1_MAXC; ++j)
-            if (j < C) {
-              const float dkh = ds * qh[j];
-              ok[j] = rk * (dkh * skv[j] - xk[j] * gx);
-              ov[j] = p * dout[j];
-              dsk_acc[j] += dkh * xk[j];
-            }
-          q1_store<T>(dk + roff * ldk + h * Dh, C, vec, ok, part);
-          q1_store<T>(dv + roff * ldv + h * Dh, C, vec, ov, part);
-        }
-      }
+    // query side: dq^ = u*s_k; d s_k += q^*u; d s_q += dq^ * x^_q; dq through the RMSNorm
+    float xq[CC];
+    q1_load<T, CC>(q0 + seq * ldq0 + h * Dh, vec, xq, part);
     float gq = 0.f;
 #pragma unroll
-    for (int j = 0; j < Q1_MAXC; ++j)
-      if (j < C) {
-#pragma unroll
-        for (int o = 4; o < 64; o <<= 1) dqh[j] += __shfl_xor(dqh[j], o, 64);
-        gq += dqh[j] * sqv[j] * xq[j];
-      }
-    gq += __shfl_xor(gq, 1, 64); gq += __shfl_xor(gq, 2, 64);
-    gq /= Dh;
+    for (int j = 0; j < CC; ++j) {
+      u[j] = kgrp_sum(u[j]);
+      xq[j] *= rq;
+      gq += u[j] * skl[j] * sql[j] * xq[j];
+    }
+    gq = quad_sum(gq) / Dh;
     if (kg == 0) {
-      float oq[Q1_MAXC];
 #pragma unroll
-      for (int j = 0; j < Q1_MAXC; ++j)
-        if (j < C) { oq[j] = rq * (dqh[j] * sqv[j] - xq[j] * gq); dsq_acc[j] += dqh[j] * xq[j]; }
-      q1_store<T>(dq0 + seq * (int64_t)H * Dh + h * Dh, C, vec, oq, part);
+      for (int j = 0; j < CC; ++j) {
+        const float dqh = u[j] * skl[j];
+        atomicAdd(&red[1][part * CC + j], qs[j] * u[j]);
+        atomicAdd(&red[0][part * CC + j], dqh * xq[j]);
+        xq[j] = rq * (dqh * sql[j] - xq[j] * gq);
+      }
+      q1_store<T, CC>(dq0 + seq * (int64_t)H * Dh + h * Dh, vec, xq, part);
     }
   }
-  // flush: sum over the 16 key groups (dsk) / take group 0 (dsq), then over the 4 waves, one atomic per channel per block
-  for (int t = threadIdx.x; t < 2 * 4 * Q1_MAXC; t += 256) ((float*)red)[t] = 0.f;
   __syncthreads();
-#pragma unroll
-  for (int j = 0; j < Q1_MAXC; ++j)
-    if (j < C) {
-      float a = dsk_acc[j];
-#pragma unroll
-      for (int o = 4; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
-      if (kg == 0) { atomicAdd(&red[1][part * Q1_MAXC + j], a); atomicAdd(&red[0][part * Q1_MAXC + j], dsq_acc[j]); }
-    }
-  __syncthreads();
-  for (int t = threadIdx.x; t < 4 * C; t += 256) {
-    const int pt = t / C, j = t - pt * C;
-    const int ch = q1_chan<T>(j, pt, C, vec);
-    atomicAdd(dsq + ch, red[0][pt * Q1_MAXC + j]);
-    atomicAdd(dsk + ch, red[1][pt * Q1_MAXC + j]);
+  for (int t = threadIdx.x; t < 4 * CC; t += 256) {
+    const int pt = t / CC, j = t - pt * CC;
+    const int ch = q1_chan<T, CC>(j, pt, vec);
+    atomicAdd(dsq + ch, red[0][t]);
+    atomicAdd(dsk + ch, red[1][t]);
   }
 }
 template <typename T>
@@ -1286,13 +1278,17 @@ void k_attn_q1_bwd(spa3d_ctx* c, const T* q0, int64_t ldq0, const T* k, const T*
                    const float* km, int64_t nseq, int S, int H, int Dh, const float* p0, const T* d_o0, T* dq0, T* dk, T* dv, float* dsq,
                    float* dsk) {
   if (c->dry || nseq == 0) return;
+  if (S > Q1_MAXS || Dh % 4 || Dh > 128) { if (!c->hip_err) { c->hip_err = -3; c->err = "attn_q1: S <= 320 and Dh % 4 == 0, Dh <= 128 required"; } return; }
   const int64_t nprob = nseq * H;
-  unsigned g = (unsigned)std::min<int64_t>(cdiv(nprob, 4), 2048);
+  unsigned g = (unsigned)std::min<int64_t>(cdiv(nprob, 4), 4096);
   constexpr int NV = VecOf<T>::N;
   const int vec = (Dh % (4 * NV) == 0 && ldk % NV == 0 && ldv % NV == 0 && ldq0 % NV == 0 &&
                    ((((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)dk) | ((uintptr_t)dv) | ((uintptr_t)q0) | ((uintptr_t)d_o0) |
                      ((uintptr_t)dq0)) & 15) == 0) ? 1 : 0;
-  attn_q1_bwd_kernel<T><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, Dh, p0, d_o0, dq0, dk, dv, dsq, dsk, vec);
+#define Q1B(CCv) attn_q1_bwd_kernel<T, CCv><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, p0, d_o0, dq0, dk, dv, dsq, dsk, vec)
+  switch (Dh / 4) { case 24: Q1B(24); break; case 16: Q1B(16); break; case 32: Q1B(32); break; case 8: Q1B(8); break; case 4: Q1B(4); break;
+    case 2: Q1B(2); break; default: if (!c->hip_err) { c->hip_err = -3; c->err = "attn_q1: unsupported head width"; } return; }
+#undef Q1B
   SPA_LAUNCH_CHECK(c);
 }
 // dst[i*stride_rows][:] += src[i][:]
