@@ -30,6 +30,7 @@ struct NtArgs {
   int64_t M; int N; int K; int64_t lda, ldb, ldc;
   const float* bias; const bf16_t* aux; bf16_t* pre_out; int epi; int out_f32; int accumulate; float alpha;
   int tiles_m, tiles_n, crow_group, crow_skip;
+  int dbg;  // experiments only (SPA3D_NT_DBG): 1 = skip the epilogue stores
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
@@ -1126,6 +1127,275 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NtArgs g) {
   if (team == 0) __builtin_amdgcn_s_barrier();  // matches team 1's extra barrier
 }
 
+// =================================================================================================================
+// 256x256x64, 8 waves, 8-phase schedule (cdna_hip_programming.md "The 256^2 8-phase template"), written for this
+// library's operand layout (A [M][K], Bt [N][K], XOR-swizzled 128-B LDS rows, swapped-operand MFMA).
+//   waves 2(M) x 4(N), 128x64 per wave; a K-tile is four half-tiles of 16 KiB, split by NEED, not by position:
+//     A-h0 / A-h1 = the first / second 64 rows of each wave-row's 128;  B-h0 / B-h1 = the first / second 32 columns of each
+//     wave-column's 64.  Phase p of K-tile t works on one quadrant of the wave's output:
+//       P0: read B-q0 (4 ds_read_b128, retired before the barrier), A-q0 (8);  16 MFMA  (rows 0-63,   cols 0-31)
+//       P1: read B-q1 (4);                                                      16 MFMA  (rows 0-63,   cols 32-63)
+//       P2: read A-q1 (8);                                                      16 MFMA  (rows 64-127, cols 32-63)
+//       P3: --                                                                  16 MFMA  (rows 64-127, cols 0-31)
+//     LDS: A in a 3-slot ring, B double-buffered (160 KiB / 144 KiB).  Everything issued during K-tile t is for K-tile t+2:
+//       P0: A-h0(t+2), A-h1(t+2) into the ring slot last read in K-tile t-1;  P1: B-h0(t+2) (its slot's last reads retired before
+//       P0's barrier);  P3: B-h1(t+2) (last read in P1).  The A panel is the operand streamed from HBM: it gets a full two
+//       K-tiles of lead; the weights come from L2.
+//   One counted wait per K-tile, in P3 before its first barrier: vmcnt(#LDS-DMA of one K-tile) leaves K-tile t+2 in flight and
+//   retires all of K-tile t+1, which is first read one phase later.  Two raw s_barrier per phase; the wave-row-1 waves run
+//   one barrier behind, so on every SIMD one wave is in its MFMA section while the other is in its read/stage section.
+// =================================================================================================================
+// 8 consecutive columns of one output row: alpha/bias, optional pre-activation copy, GELU, residual / GELU-gradient, store.
+__device__ __forceinline__ void nt_store8(const NtArgs& g, int64_t gm, int gn, float (&v)[8], const float (&b8)[8]) {
+  int64_t crow = gm;
+  if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = g.alpha * v[r] + b8[r];
+  const int64_t ci = crow * g.ldc + gn;
+  if (g.pre_out) {
+    uint4 p4; unsigned* pp = (unsigned*)&p4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pp[r] = (unsigned)f2bf(v[2 * r]) | ((unsigned)f2bf(v[2 * r + 1]) << 16);
+    *(uint4*)(g.pre_out + ci) = p4;
+  }
+  if (g.epi == EPI_GELU) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_f(v[r]);
+  }
+  if (g.aux) {
+    const uint4 x4 = *(const uint4*)(g.aux + ci); const unsigned* xp = (const unsigned*)&x4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float xa = __uint_as_float(xp[r] << 16), xb = __uint_as_float(xp[r] & 0xffff0000u);
+      if (g.epi == EPI_MUL_GELU_GRAD) { v[2 * r] *= gelu_tanh_grad_f(xa); v[2 * r + 1] *= gelu_tanh_grad_f(xb); }
+      else { v[2 * r] += xa; v[2 * r + 1] += xb; }
+    }
+  }
+  if (g.out_f32) {
+    float4* cp = (float4*)((float*)g.C + ci);
+    if (g.accumulate) { const float4 o0 = cp[0], o1 = cp[1];
+      v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w; v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w; }
+    cp[0] = make_float4(v[0], v[1], v[2], v[3]); cp[1] = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    uint4* cp = (uint4*)((bf16_t*)g.C + ci);
+    if (g.accumulate) { const uint4 o4 = *cp; const unsigned* op = (const unsigned*)&o4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[2 * r] += __uint_as_float(op[r] << 16); v[2 * r + 1] += __uint_as_float(op[r] & 0xffff0000u); } }
+    uint4 o4; unsigned* op = (unsigned*)&o4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) op[r] = (unsigned)f2bf(v[2 * r]) | ((unsigned)f2bf(v[2 * r + 1]) << 16);
+    *cp = o4;
+  }
+}
+
+__device__ __forceinline__ void nt_store4(const NtArgs& g, int64_t gm, int gn, const f32x4& a) {
+  if (gm >= g.M || gn >= g.N) return;
+  int64_t crow = gm;
+  if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
+  float vv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) vv[r] = g.alpha * a[r];
+  if (g.bias) { const float4 b4 = *(const float4*)(g.bias + gn); vv[0] += b4.x; vv[1] += b4.y; vv[2] += b4.z; vv[3] += b4.w; }
+  const int64_t ci = crow * g.ldc + gn;
+  if (g.pre_out) { u16x4 p4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p4[r] = f2bf(vv[r]);
+    *(u16x4*)(g.pre_out + ci) = p4; }
+  if (g.epi == EPI_GELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vv[r] = gelu_tanh_f(vv[r]);
+  }
+  if (g.aux) {
+    const u16x4 x4 = *(const u16x4*)(g.aux + ci);
+    if (g.epi == EPI_MUL_GELU_GRAD) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vv[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vv[r] += bf2f(x4[r]);
+    }
+  }
+  if (g.out_f32) {
+    float4* cp = (float4*)((float*)g.C + ci);
+    if (g.accumulate) { const float4 o = *cp; vv[0] += o.x; vv[1] += o.y; vv[2] += o.z; vv[3] += o.w; }
+    *cp = make_float4(vv[0], vv[1], vv[2], vv[3]);
+  } else {
+    u16x4* cp = (u16x4*)((bf16_t*)g.C + ci);
+    if (g.accumulate) { const u16x4 o = *cp;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vv[r] += bf2f(o[r]); }
+    u16x4 o4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o4[r] = f2bf(vv[r]);
+    *cp = o4;
+  }
+}
+
+#define NT8P_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define NT8P_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define NT8P_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
+
+// WMT x WNT = 16x16 output tiles per wave; waves 2(M) x 4(N); tile = (32 WMT) x (64 WNT): <8,4> = 256x256, <4,6> = 128x384
+// (N = 384 in ONE tile: the A panel is read from HBM exactly once).  64 KiB per LDS buffer in both.
+template <int WMT, int WNT>
+__global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(NtArgs g) {
+  constexpr int BM = 32 * WMT, BN = 64 * WNT;
+  constexpr int NA = WMT / 4, NB = WNT / 2;   // LDS-DMA per thread per A / B half-tile
+  constexpr int HM = WMT / 2, HN = WNT / 2;   // tiles per quadrant side
+  constexpr int ASLOT = BM * 128, BBUF = BN * 128, BOFF = 3 * ASLOT;  // A ring of 3, then two B buffers
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int tm = (idx / g.tiles_n) * 8 + xcd, tn = idx % g.tiles_n;
+  if (tm >= g.tiles_m) return;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sr = lane >> 3, scp = lane & 7;
+  const int sc = (scp ^ sr) * 8;
+  // staging: 8-row group gi = 8i + w of a half-tile.  A-h: wave-row block gi / WMT, group gi % WMT; B-h: wave-column block gi / WNT
+  const bf16_t* pa[2][NA]; const bf16_t* pb[2][NB];
+  int la[2][NA], lb[2][NB];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int gi = i * 8 + w, ra = (gi / WMT) * (WMT * 16) + h * (WMT * 8) + (gi % WMT) * 8;
+      int64_t am = m0 + ra + sr; if (am > g.M - 1) am = g.M - 1;
+      pa[h][i] = g.A + am * g.lda + sc; la[h][i] = ra * 128;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int gi = i * 8 + w, rb = (gi / WNT) * (WNT * 16) + h * (WNT * 8) + (gi % WNT) * 8;
+      int bn = n0 + rb + sr; if (bn > g.N - 1) bn = g.N - 1;
+      pb[h][i] = g.Bt + (int64_t)bn * g.ldb + sc; lb[h][i] = BOFF + rb * 128;
+    }
+  }
+  auto stageA = [&](int kt, int slot) {  // both halves of K-tile kt
+    char* base = smem + slot * ASLOT;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < NA; ++i) GLDS16(pa[h][i] + kt * 64, base + la[h][i]);
+  };
+  auto stageB = [&](int h, int kt) {
+    char* base = smem + (kt & 1) * BBUF;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) GLDS16(pb[h][i] + kt * 64, base + lb[h][i]);
+  };
+  f32x4 acc[WMT][WNT];
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nt = g.K / 64;
+  constexpr int NKT = 2 * NA + 2 * NB;  // LDS-DMA per thread per K-tile
+  stageA(0, 0); stageB(0, 0); stageB(1, 0);
+  if (nt > 1) { stageA(1, 1); stageB(0, 1); stageB(1, 1); NT8P_WAIT_VM(NKT); }
+  else NT8P_WAIT_VM(0);
+  NT8P_BAR();                 // K-tile 0 is visible to every wave
+  if (wr == 1) NT8P_BAR();    // the stagger: wave-row 1 runs one barrier behind
+  const int a_off = (wr * WMT * 16 + fr) * 128, b_off = BOFF + (wc * WNT * 16 + fr) * 128;
+  const int x0 = ((fq) ^ (fr & 7)) * 16, x1 = ((4 + fq) ^ (fr & 7)) * 16;
+  bf16x8 aq[HM][2], bq0[HN][2], bq1[HN][2];
+#define NT8P_MFMA(AI, BJ, BQ)                                                                                                         \
+  __builtin_amdgcn_s_setprio(1);                                                                                                      \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < HM; ++i) _Pragma("unroll") for (int j = 0; j < HN; ++j) \
+      acc[(AI) + i][(BJ) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BQ[j][ks], aq[i][ks], acc[(AI) + i][(BJ) + j], 0, 0, 0);       \
+  __builtin_amdgcn_s_setprio(0);
+  int aslot = 0, aslot2 = 2;  // ring slots of K-tiles t and t+2
+  for (int t = 0; t < nt; ++t) {
+    const char* sa = smem + aslot * ASLOT;
+    const char* sb = smem + (t & 1) * BBUF;
+    // ---------------- P0
+#pragma unroll
+    for (int j = 0; j < HN; ++j) { bq0[j][0] = *(const bf16x8*)(sb + b_off + j * 2048 + x0); bq0[j][1] = *(const bf16x8*)(sb + b_off + j * 2048 + x1); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < HM; ++i) { aq[i][0] = *(const bf16x8*)(sa + a_off + i * 2048 + x0); aq[i][1] = *(const bf16x8*)(sa + a_off + i * 2048 + x1); }
+    if (t + 2 < nt) stageA(t + 2, aslot2);
+    NT8P_WAIT_LGKM(2 * HM);  // the B-q0 reads have returned: B-h0 may be restaged one phase from now
+    NT8P_BAR();
+    NT8P_WAIT_LGKM(0);
+    NT8P_MFMA(0, 0, bq0)
+    NT8P_BAR();
+    // ---------------- P1
+#pragma unroll
+    for (int j = 0; j < HN; ++j) { bq1[j][0] = *(const bf16x8*)(sb + b_off + (HN + j) * 2048 + x0); bq1[j][1] = *(const bf16x8*)(sb + b_off + (HN + j) * 2048 + x1); }
+    if (t + 2 < nt) stageB(0, t + 2);
+    NT8P_BAR();
+    NT8P_WAIT_LGKM(0);
+    NT8P_MFMA(0, HN, bq1)
+    NT8P_BAR();
+    // ---------------- P2
+#pragma unroll
+    for (int i = 0; i < HM; ++i) { aq[i][0] = *(const bf16x8*)(sa + a_off + (HM + i) * 2048 + x0); aq[i][1] = *(const bf16x8*)(sa + a_off + (HM + i) * 2048 + x1); }
+    NT8P_BAR();
+    NT8P_WAIT_LGKM(0);
+    NT8P_MFMA(HM, HN, bq1)
+    NT8P_BAR();
+    // ---------------- P3
+    if (t + 2 < nt) { stageB(1, t + 2); NT8P_WAIT_VM(NKT); }  // K-tile t+1 has landed (this wave's part); t+2 stays in flight
+    else NT8P_WAIT_VM(0);
+    NT8P_BAR();
+    NT8P_MFMA(HM, 0, bq0)
+    NT8P_BAR();
+    aslot = aslot == 2 ? 0 : aslot + 1; aslot2 = aslot2 == 2 ? 0 : aslot2 + 1;
+  }
+#undef NT8P_MFMA
+  if (wr == 0) NT8P_BAR();  // pairs with wave-row 1's extra barrier
+  if (g.dbg == 1 && acc[0][0][0] != 12345.678f) return;
+  // ---- epilogue through wave-private LDS (the K-loop's buffers are dead: every wave has passed the final barrier).
+  // Region per wave: [8 WMT rows][4 WNT chunks of 16 B] f32 (16 KiB / 12 KiB), chunk index swizzled with the row so that both the
+  // accumulator writes and the row-wise reads spread over the banks.  Two passes (upper / lower half of the wave's rows); read
+  // back as 8 columns per lane, rows contiguous: every store instruction writes whole 128-B / 192-B row segments.
+  constexpr int RB = WNT * 64;           // row bytes
+  constexpr int CPR = WNT * 2;           // 8-column groups per row
+  char* reg = smem + w * 16384;
+  auto swz = [](int chunk, int row) { return WNT == 4 ? (chunk ^ (row & 15)) : ((chunk & ~7) | ((chunk & 7) ^ ((row >> 1) & 7))); };
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int i = 0; i < HM; ++i)
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) *(f32x4*)(reg + (i * 16 + fr) * RB + (swz(j * 4 + fq, i * 16 + fr) << 4)) = acc[half * HM + i][j];
+    __builtin_amdgcn_wave_barrier();  // same wave, LDS is in order: only the compiler must keep the order
+#pragma unroll 2
+    for (int it = 0; it < WMT * WNT / 4; ++it) {
+      const int id = it * 64 + lane, row = id / CPR, c8 = id - row * CPR;
+      const f32x4 v0 = *(const f32x4*)(reg + row * RB + (swz(2 * c8, row) << 4));
+      const f32x4 v1 = *(const f32x4*)(reg + row * RB + (swz(2 * c8 + 1, row) << 4));
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      const int64_t gm = m0 + wr * (WMT * 16) + half * (WMT * 8) + row;
+      const int gn = n0 + wc * (WNT * 16) + c8 * 8;
+      if (gm < g.M && gn < g.N) {
+        float b8[8];
+        if (g.bias) { const float4 b0 = *(const float4*)(g.bias + gn), b1 = *(const float4*)(g.bias + gn + 4);
+          b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w; }
+        else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) b8[r] = 0.f;
+        }
+        nt_store8(g, gm, gn, v, b8);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int WMT, int WNT>
+static void launch_nt8p(spa3d_ctx* c, const NtArgs& g) {
+  NtArgs g2 = g; g2.tiles_m = (int)((g.M + 32 * WMT - 1) / (32 * WMT)); g2.tiles_n = g.N / (64 * WNT);
+  const int64_t b2 = (int64_t)((g2.tiles_m + 7) / 8) * 8 * g2.tiles_n;
+  static bool attr = false;
+  constexpr int LDS = (3 * 32 * WMT + 2 * 64 * WNT) * 128;  // 160 KiB <8,4>, 144 KiB <4,6>
+  if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<WMT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  gemm_nt8p_kernel<WMT, WNT><<<(unsigned)b2, 512, LDS, c->stream>>>(g2);
+}
+
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
@@ -1147,6 +1417,7 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   g.bias = d.bias; g.aux = (const bf16_t*)d.aux; g.pre_out = (bf16_t*)d.pre_out; g.epi = d.epi; g.out_f32 = d.out_f32; g.accumulate = d.accumulate; g.alpha = d.alpha;
   g.tiles_m = (int)((d.M + 127) / 128); g.tiles_n = (d.N + 127) / 128;
   g.crow_group = d.crow_group; g.crow_skip = d.crow_skip;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SPA3D_NT_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
   const int64_t blocks = (int64_t)((g.tiles_m + 7) / 8) * 8 * g.tiles_n;
   if (blocks > 0x7fffffffLL) return false;
   static bool attr_set = false;
@@ -1161,6 +1432,12 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
     if (!attr5) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); attr5 = true; }
     if (c->nt_ring >= 3) gemm_nt_ring_kernel<<<(unsigned)std::min(256, g2.tiles_m), 512, 163840, c->stream>>>(g2);
     else gemm_nt_pp_kernel<<<(unsigned)std::min(256, g2.tiles_m), 512, 163840, c->stream>>>(g2);
+    SPA_LAUNCH_CHECK(c);
+    return true;
+  }
+  // 8-phase kernels: 256x256 when 256 | N, 128x384 when 384 | N (see the kernel header for the measurements)
+  if (c->nt_8p && (d.N % 256 == 0 || d.N % 384 == 0) && (d.M >= 256 * 64 || c->nt_8p == 2) && c->nt_8p != 3) {
+    if (d.N % 256 == 0) launch_nt8p<8, 4>(c, g); else launch_nt8p<4, 6>(c, g);
     SPA_LAUNCH_CHECK(c);
     return true;
   }

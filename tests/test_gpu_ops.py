@@ -369,6 +369,19 @@ def test_linear_tiled_nt_double_buffered(lib, monkeypatch, M, N, K, act, res, bi
 
 
 @pytest.mark.parametrize('M,N,K,act,res,bias', [(4133, 2304, 384, 0, False, False), (1000, 1536, 384, 1, False, True),
+                                                (2050, 768, 256, 0, True, True), (700, 1280, 1536, 0, False, True), (300, 256, 64, 0, False, False),
+                                                (513, 512, 128, 0, False, True), (256, 256, 192, 0, True, False), (9000, 1280, 768, 0, True, True),
+                                                (4133, 384, 768, 0, True, True), (900, 1152, 256, 1, False, True), (130, 384, 64, 0, False, False),
+                                                (2050, 384, 1536, 0, True, True), (777, 384, 128, 0, False, True)])
+def test_linear_tiled_nt_8phase(lib, monkeypatch, M, N, K, act, res, bias):
+  """the 8-phase kernels (256x256 when 256 | N, 128x384 when 384 | N; counted vmcnt, staggered wave rows), forced on for any M with SPA3D_NT_8P=2;
+  K = 64 / 128 / 192 exercise the prologue and tail paths of the schedule (1, 2, 3 K-tiles)"""
+  monkeypatch.setenv('SPA3D_NT_RING', '0')
+  monkeypatch.setenv('SPA3D_NT_8P', '2')
+  test_linear_tiled_nt(lib, M, N, K, act, res, bias)
+
+
+@pytest.mark.parametrize('M,N,K,act,res,bias', [(4133, 2304, 384, 0, False, False), (1000, 1536, 384, 1, False, True),
                                                 (2050, 768, 256, 0, True, True), (700, 1280, 1536, 0, False, True), (300, 256, 64, 0, False, False)])
 def test_linear_tiled_nt_256(lib, monkeypatch, M, N, K, act, res, bias):
   """the 256x256 8-wave kernel (N % 256 == 0), forced on for small M with SPA3D_NT_256=2"""
