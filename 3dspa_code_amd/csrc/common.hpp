@@ -32,6 +32,20 @@ __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x * x);
 }
 
+// bf16-path variants (tiled GEMM epilogues only; the fp32 parity path keeps tanhf): gelu(x) = x*s, s = sigmoid(2u) = 1/(1+exp(-2u)),
+// gelu'(x) = s*(1 + 2x(1-s)u'), one v_exp_f32 + one v_rcp_f32 (abs error ~1e-7, far below bf16 rounding).
+__device__ __forceinline__ float gelu_sigmoid_2u(float x) {
+  const float c2 = 2.0f * 0.7978845608028654f;
+  const float u2 = c2 * (x + 0.044715f * x * x * x);
+  return __builtin_amdgcn_rcpf(1.0f + __expf(-u2));
+}
+__device__ __forceinline__ float gelu_tanh_fast_f(float x) { return x * gelu_sigmoid_2u(x); }
+__device__ __forceinline__ float gelu_tanh_grad_fast_f(float x) {
+  const float s = gelu_sigmoid_2u(x);
+  const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+  return s * (1.0f + 2.0f * x * (1.0f - s) * du);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -72,7 +86,7 @@ struct Arena {  // bump allocator over the caller's workspace; dry mode only cou
 
 // live per-kernel-class timing with HIP events on the launch stream (bench.py "roofline"; off by default)
 enum { PROF_GEMM_NT = 0, PROF_GEMM_TN = 1, PROF_GEMM_GENERIC = 2, PROF_ATTN_FWD = 3, PROF_ATTN_BWD = 4, PROF_NCLS = 5 };
-struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; };
+struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; int64_t tag[4] = {0, 0, 0, 0}; };  // tag: M, N, K, flags (GEMMs)
 struct Prof {
   bool on = false;
   std::vector<hipEvent_t> pool; size_t used = 0;
@@ -116,6 +130,7 @@ struct ProfScope {  // records an event pair around the launches issued in its l
     if (!r.e0 || !r.e1) { on = false; return; }
     (void)hipEventRecord(r.e0, c->stream);
   }
+  void tag(int64_t a, int64_t b, int64_t c2, int64_t d) { r.tag[0] = a; r.tag[1] = b; r.tag[2] = c2; r.tag[3] = d; }
   ~ProfScope() { if (on) { (void)hipEventRecord(r.e1, c->stream); c->prof.recs.push_back(r); } }
 };
 

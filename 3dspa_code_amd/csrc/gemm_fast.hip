@@ -141,14 +141,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
     }
     if (g.epi == EPI_GELU) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_f(v[r]);
+      for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_fast_f(v[r]);
     }
     if (g.aux) {
       const uint4 x4 = *(const uint4*)(g.aux + ci); const unsigned* xp = (const unsigned*)&x4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float xa = __uint_as_float(xp[r] << 16), xb = __uint_as_float(xp[r] & 0xffff0000u);
-        if (g.epi == EPI_MUL_GELU_GRAD) { v[2 * r] *= gelu_tanh_grad_f(xa); v[2 * r + 1] *= gelu_tanh_grad_f(xb); }
+        if (g.epi == EPI_MUL_GELU_GRAD) { v[2 * r] *= gelu_tanh_grad_fast_f(xa); v[2 * r + 1] *= gelu_tanh_grad_fast_f(xb); }
         else { v[2 * r] += xa; v[2 * r + 1] += xb; }
       }
     }
@@ -285,13 +285,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_astat_kernel(NtArgs g) {
             *(u16x4*)(g.pre_out + ci) = p4; }
           if (g.epi == EPI_GELU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast_f(v[r]);
           }
           if (g.aux) {
             const u16x4 x4 = *(const u16x4*)(g.aux + ci);
             if (g.epi == EPI_MUL_GELU_GRAD) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
+              for (int r = 0; r < 4; ++r) v[r] *= gelu_tanh_grad_fast_f(bf2f(x4[r]));
             } else {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] += bf2f(x4[r]);
@@ -427,13 +427,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_persist_kernel(NtArgs g) {
           *(u16x4*)(g.pre_out + ci) = p4; }
         if (g.epi == EPI_GELU) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) vv[r] = gelu_tanh_f(vv[r]);
+          for (int r = 0; r < 4; ++r) vv[r] = gelu_tanh_fast_f(vv[r]);
         }
         if (g.aux) {
           const u16x4 x4 = *(const u16x4*)(g.aux + ci);
           if (g.epi == EPI_MUL_GELU_GRAD) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) vv[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
+            for (int r = 0; r < 4; ++r) vv[r] *= gelu_tanh_grad_fast_f(bf2f(x4[r]));
           } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) vv[r] += bf2f(x4[r]);
@@ -543,13 +543,13 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_occ_kernel(NtArgs g) {
         *(u16x4*)(g.pre_out + ci) = p4; }
       if (g.epi == EPI_GELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vv[r] = gelu_tanh_f(vv[r]);
+        for (int r = 0; r < 4; ++r) vv[r] = gelu_tanh_fast_f(vv[r]);
       }
       if (g.aux) {
         const u16x4 x4 = *(const u16x4*)(g.aux + ci);
         if (g.epi == EPI_MUL_GELU_GRAD) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) vv[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
+          for (int r = 0; r < 4; ++r) vv[r] *= gelu_tanh_grad_fast_f(bf2f(x4[r]));
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) vv[r] += bf2f(x4[r]);
@@ -661,13 +661,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(NtArgs g) {
         *(u16x4*)(g.pre_out + ci) = p4; }
       if (g.epi == EPI_GELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vv[r] = gelu_tanh_f(vv[r]);
+        for (int r = 0; r < 4; ++r) vv[r] = gelu_tanh_fast_f(vv[r]);
       }
       if (g.aux) {
         const u16x4 x4 = *(const u16x4*)(g.aux + ci);
         if (g.epi == EPI_MUL_GELU_GRAD) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) vv[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
+          for (int r = 0; r < 4; ++r) vv[r] *= gelu_tanh_grad_fast_f(bf2f(x4[r]));
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) vv[r] += bf2f(x4[r]);
@@ -790,13 +790,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_astat2_kernel(NtArgs g) {
               *(u16x4*)(g.pre_out + ci) = p4; }
             if (g.epi == EPI_GELU) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+              for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast_f(v[r]);
             }
             if (g.aux) {
               const u16x4 x4 = *(const u16x4*)(g.aux + ci);
               if (g.epi == EPI_MUL_GELU_GRAD) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
+                for (int r = 0; r < 4; ++r) v[r] *= gelu_tanh_grad_fast_f(bf2f(x4[r]));
               } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += bf2f(x4[r]);
@@ -942,13 +942,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(NtArgs g) {
             *(u16x4*)(g.pre_out + ci) = p4; }
           if (g.epi == EPI_GELU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast_f(v[r]);
           }
           if (g.aux) {
             const u16x4 x4 = *(const u16x4*)(g.aux + ci);
             if (g.epi == EPI_MUL_GELU_GRAD) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
+              for (int r = 0; r < 4; ++r) v[r] *= gelu_tanh_grad_fast_f(bf2f(x4[r]));
             } else {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] += bf2f(x4[r]);
@@ -1093,13 +1093,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NtArgs g) {
             *(u16x4*)(g.pre_out + ci) = p4; }
           if (g.epi == EPI_GELU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast_f(v[r]);
           }
           if (g.aux) {
             const u16x4 x4 = *(const u16x4*)(g.aux + ci);
             if (g.epi == EPI_MUL_GELU_GRAD) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
+              for (int r = 0; r < 4; ++r) v[r] *= gelu_tanh_grad_fast_f(bf2f(x4[r]));
             } else {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] += bf2f(x4[r]);
@@ -1146,7 +1146,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NtArgs g) {
 //   one barrier behind, so on every SIMD one wave is in its MFMA section while the other is in its read/stage section.
 // =================================================================================================================
 // 8 consecutive columns of one output row: alpha/bias, optional pre-activation copy, GELU, residual / GELU-gradient, store.
-__device__ __forceinline__ void nt_store8(const NtArgs& g, int64_t gm, int gn, float (&v)[8], const float (&b8)[8]) {
+template <bool AUXPRE = false>
+__device__ __forceinline__ void nt_store8(const NtArgs& g, int64_t gm, int gn, float (&v)[8], const float (&b8)[8], uint4 auxpre = uint4{0, 0, 0, 0}) {
   int64_t crow = gm;
   if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
 #pragma unroll
@@ -1160,14 +1161,14 @@ __device__ __forceinline__ void nt_store8(const NtArgs& g, int64_t gm, int gn, f
   }
   if (g.epi == EPI_GELU) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_f(v[r]);
+    for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_fast_f(v[r]);
   }
   if (g.aux) {
-    const uint4 x4 = *(const uint4*)(g.aux + ci); const unsigned* xp = (const unsigned*)&x4;
+    const uint4 x4 = AUXPRE ? auxpre : *(const uint4*)(g.aux + ci); const unsigned* xp = (const unsigned*)&x4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float xa = __uint_as_float(xp[r] << 16), xb = __uint_as_float(xp[r] & 0xffff0000u);
-      if (g.epi == EPI_MUL_GELU_GRAD) { v[2 * r] *= gelu_tanh_grad_f(xa); v[2 * r + 1] *= gelu_tanh_grad_f(xb); }
+      if (g.epi == EPI_MUL_GELU_GRAD) { v[2 * r] *= gelu_tanh_grad_fast_f(xa); v[2 * r + 1] *= gelu_tanh_grad_fast_f(xb); }
       else { v[2 * r] += xa; v[2 * r + 1] += xb; }
     }
   }
@@ -1203,13 +1204,13 @@ __device__ __forceinline__ void nt_store4(const NtArgs& g, int64_t gm, int gn, c
     *(u16x4*)(g.pre_out + ci) = p4; }
   if (g.epi == EPI_GELU) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) vv[r] = gelu_tanh_f(vv[r]);
+    for (int r = 0; r < 4; ++r) vv[r] = gelu_tanh_fast_f(vv[r]);
   }
   if (g.aux) {
     const u16x4 x4 = *(const u16x4*)(g.aux + ci);
     if (g.epi == EPI_MUL_GELU_GRAD) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) vv[r] *= gelu_tanh_grad_f(bf2f(x4[r]));
+      for (int r = 0; r < 4; ++r) vv[r] *= gelu_tanh_grad_fast_f(bf2f(x4[r]));
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) vv[r] += bf2f(x4[r]);
@@ -1363,8 +1364,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(NtArgs g) {
 #pragma unroll
       for (int j = 0; j < WNT; ++j) *(f32x4*)(reg + (i * 16 + fr) * RB + (swz(j * 4 + fq, i * 16 + fr) << 4)) = acc[half * HM + i][j];
     __builtin_amdgcn_wave_barrier();  // same wave, LDS is in order: only the compiler must keep the order
-#pragma unroll 2
-    for (int it = 0; it < WMT * WNT / 4; ++it) {
+    constexpr int NIT = WMT * WNT / 4;
+    // residual / pre-activation operand: all of this pass's loads go out first (a load per iteration inside the loop keeps only
+    // two in flight per wave, and nothing else runs on the CU to hide them)
+    uint4 auxv[NIT];
+    if (g.aux) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int id = it * 64 + lane, row = id / CPR, c8 = id - row * CPR;
+        const int64_t gm = m0 + wr * (WMT * 16) + half * (WMT * 8) + row;
+        const int gn = n0 + wc * (WNT * 16) + c8 * 8;
+        auxv[it] = uint4{0, 0, 0, 0};
+        if (gm < g.M && gn < g.N) {
+          int64_t crow = gm;
+          if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
+          auxv[it] = *(const uint4*)(g.aux + crow * g.ldc + gn);
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
       const int id = it * 64 + lane, row = id / CPR, c8 = id - row * CPR;
       const f32x4 v0 = *(const f32x4*)(reg + row * RB + (swz(2 * c8, row) << 4));
       const f32x4 v1 = *(const f32x4*)(reg + row * RB + (swz(2 * c8 + 1, row) << 4));
@@ -1379,7 +1398,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(NtArgs g) {
 #pragma unroll
           for (int r = 0; r < 8; ++r) b8[r] = 0.f;
         }
-        nt_store8(g, gm, gn, v, b8);
+        nt_store8<true>(g, gm, gn, v, b8, auxv[it]);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1423,6 +1442,7 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
   ProfScope ps(c, PROF_GEMM_NT, 2.0 * (double)d.M * d.N * d.K, ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * 2.0);
+  ps.tag(d.M, d.N, d.K, d.epi | (d.aux ? 4 : 0) | (d.pre_out ? 8 : 0) | (d.out_f32 ? 16 : 0) | (d.accumulate ? 32 : 0) | (d.crow_group ? 64 : 0) | (d.sAm != d.K ? 128 : 0));
   const int KT = d.K / 64;
   if (c->nt_ring && d.N % 128 == 0 && d.N <= 4096 && (d.M >= 256 * 512 || c->nt_ring == 2 || c->nt_ring == 4)) {
     NtArgs g2 = g; g2.tiles_m = (int)((d.M + 255) / 256); g2.tiles_n = d.N / 128;
@@ -1654,6 +1674,7 @@ bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d) {
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
   ProfScope ps(c, PROF_GEMM_TN, 2.0 * (double)M * Ki * N, ((double)M * Ki + (double)M * N) * 2.0 + (double)Ki * N * 4.0 * splits);
+  ps.tag(M, N, Ki, splits);
   gemm_tn_kernel<<<(unsigned)(tiles * ((splits + 7) / 8 * 8)), 256, 65536, c->stream>>>(g);
   SPA_LAUNCH_CHECK(c);
   return true;

@@ -12,6 +12,7 @@
 #include <map>
 
 #include "common.hpp"
+#include <cstdio>
 
 template <typename T>
 void attention_fwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq,
@@ -805,6 +806,20 @@ int spa3d_prof_read(spa3d_handle h, int32_t cls, double* out4) {
     n += 1; ms += t; fl += r.flops; by += r.bytes;
   }
   out4[0] = n; out4[1] = ms; out4[2] = fl; out4[3] = by;
+  return SPA3D_OK;
+}
+
+// Debug aid (not part of include/spa3d.h): one CSV line per profiled launch group: cls,ms,flops,bytes,tag0..3
+int spa3d_prof_dump(spa3d_handle h, const char* path) {
+  if (!h || !path) return SPA3D_ERR_ARG;
+  FILE* f = fopen(path, "w");
+  if (!f) return SPA3D_ERR_ARG;
+  for (auto& r : h->prof.recs) {
+    float t = 0.f;
+    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) { fclose(f); return SPA3D_ERR_HIP; }
+    fprintf(f, "%d,%.6f,%.6g,%.6g,%lld,%lld,%lld,%lld\n", r.cls, t, r.flops, r.bytes, (long long)r.tag[0], (long long)r.tag[1], (long long)r.tag[2], (long long)r.tag[3]);
+  }
+  fclose(f);
   return SPA3D_OK;
 }
 
