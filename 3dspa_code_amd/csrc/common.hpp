@@ -115,6 +115,8 @@ struct spa3d_ctx {
   int nt_astat2 = 0;  // two-team A-stationary NT kernel for K <= 384, N >= 512: 638 TF/s vs 667 for the single-buffer kernel, off;
                       // SPA3D_NT_ASTAT2=1 enables, =2 forces small M (tests)
   int nt_8p = 1;      // 8-phase kernels (256x256 / 128x384, counted vmcnt, staggered wave rows); 2 = also for small M, 0/3 = off
+  int tn_8p = 1;      // 8-phase TN (dW) kernels; SPA3D_TN_8P=0 disables, =2 forces (tests)
+  int tn_rounds = 0;  // 0: M-split count of the 8-phase TN kernels from the makespan model; > 0: 256 * rounds / tiles (experiments)
   int nt_ring = 0;    // persistent 256x128 kernels, measured SLOWER than the 128x128 ones (500-740 vs 660-885 TF/s), off:
                       // SPA3D_NT_RING=1 ping-pong teams (staggered by one barrier), =3 plain ring; =2 ping-pong forced for small M (tests)
   int nt_256 = 1;     // 256x256 8-wave NT kernel for N % 256 == 0 (SPA3D_NT_256=0 disables; =2 forces small M in tests)

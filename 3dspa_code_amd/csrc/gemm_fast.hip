@@ -1651,6 +1651,184 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
     }
 }
 
+// =================================================================================================================
+// TN, 8-phase form.  Output tile (64 WIT) x (128 WNT) with WIT + 2 WNT = 8: <4,2> = 256x256, <2,3> = 128x384, <6,1> = 384x128
+// (the 384-wide weight dimensions of the model fit without padding).  8 waves as 2 (i) x 4 (n), 32x32x16 MFMA.
+//   The reduction runs over "quarters" of 16 rows of m.  One quarter in LDS = four [16 rows][128 columns] sub-images (A's, then
+//   B's) in the transposed-read layout above = 16 KiB = 2 LDS-DMA per thread.  Phase q:
+//       12 (11 / 14) ds_read_b64_tr_b16 pairs of quarter q | 2 LDS-DMA of quarter q+8 | s_waitcnt vmcnt(14) (quarter q+1 landed)
+//       s_barrier | lgkmcnt(0) | 8 (6) MFMA | s_barrier
+//   Ring of 10 quarters = 160 KiB: quarter q+8 takes the slot of quarter q-2, two phases after its last read; both operands are
+//   streamed from HBM and get an 8-phase lead.  Wave-row 1 runs one barrier behind wave-row 0 (one wave of each per SIMD), so
+//   one reads/stages while the other issues MFMAs.  Hazard rules as in the NT kernel (cdna_hip_programming.md, 8-phase template).
+// =================================================================================================================
+template <int WIT, int WNT>
+__global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs g) {
+  constexpr int TI = 64 * WIT, TNN = 128 * WNT, NSA = TI / 128;
+  static_assert(TI / 128 + TNN / 128 == 4, "four sub-images per quarter");
+  constexpr int R = 10, D = 8, QB = 16384;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int xcd = blockIdx.x & 7; int jb = blockIdx.x >> 3;
+  const int ntile = g.tiles_i * g.tiles_n;
+  const int sp = (jb / ntile) * 8 + xcd; jb %= ntile;
+  if (sp >= g.splits) return;
+  const int tn = jb % g.tiles_n, ti = jb / g.tiles_n;
+  const int i0 = ti * TI, n0 = tn * TNN;
+  const int64_t mbeg = (int64_t)sp * g.rows_per_split;
+  int64_t mend = mbeg + g.rows_per_split; if (mend > g.M) mend = g.M;
+  const int nq = (int)((mend - mbeg + 15) / 16);
+  if (nq <= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3;
+
+  // ---- staging: LDS-DMA ii = 8 i2 + w of a quarter -> sub-image ii >> 2, rows 4 (ii & 3) .. +3; lane -> (row sr, physical chunk scp)
+  const int sr = lane >> 4, scp = lane & 15;
+  // The steady state is a pointer increment per LDS-DMA (the read/stage section has to fit under the other wave-row's 8 MFMAs);
+  // the row-bound test exists only in the tail branch, and the B-row remap (row -> row + (row / G + 1) * S) is carried incrementally.
+  // Named scalars, not arrays: an array of pointers selected against g.zero is demoted to scratch (vmcnt(0) in the loop).
+  const bf16_t *spA, *spB; int64_t stepA, stepB, skipA = 0, skipB = 0; int ldsA, ldsB, r16A, r16B, boffA = 0, boffB = 0;
+  auto setup = [&](int i2, const bf16_t*& sp, int64_t& step, int64_t& skip, int& ldso, int& r16o, int& boff) {
+    const int ii = i2 * 8 + w, si = ii >> 2, rg = ii & 3;
+    const int r16 = rg * 4 + sr;
+    const int ch = scp ^ (((r16 & 3) << 2) | ((r16 >> 2) & 3));
+    r16o = r16; ldso = si * 4096 + rg * 1024;
+    const int64_t m = mbeg + r16;
+    if (si < NSA) {
+      int ca = i0 + si * 128 + ch * 8; if (ca > g.Ki - 8) ca = g.Ki - 8;
+      sp = g.A + m * g.lda + ca; step = 16 * g.lda;
+    } else {
+      int cb = n0 + (si - NSA) * 128 + ch * 8; if (cb > g.N - 8) cb = g.N - 8;
+      int64_t row = m;
+      if (g.brow_group > 0) { const int64_t grp = m / g.brow_group; boff = (int)(m - grp * g.brow_group); row = m + (grp + 1) * (int64_t)g.brow_skip;
+        skip = (int64_t)g.brow_skip * g.ldb; }
+      sp = g.B + row * g.ldb + cb; step = 16 * g.ldb;
+    }
+  };
+  setup(0, spA, stepA, skipA, ldsA, r16A, boffA);
+  setup(1, spB, stepB, skipB, ldsB, r16B, boffB);
+  const int nq_full = (int)((mend - mbeg) / 16);  // quarters whose 16 rows all exist
+  const bool remap = g.brow_group > 0;
+  const int G = g.brow_group;
+  int q_issue = 0, slot_issue = 0;
+  auto stage = [&]() {  // quarters are issued strictly in order
+    char* base = smem + slot_issue * QB;
+    if (q_issue < nq_full) {
+      GLDS16(spA, base + ldsA);
+      GLDS16(spB, base + ldsB);
+    } else {  // rows past the end contribute exactly 0 (both operands read the zero page)
+      const int64_t mq = mbeg + (int64_t)q_issue * 16;
+      const bf16_t* pa = (mq + r16A < mend) ? spA : g.zero;
+      const bf16_t* pb = (mq + r16B < mend) ? spB : g.zero;
+      GLDS16(pa, base + ldsA);
+      GLDS16(pb, base + ldsB);
+    }
+    spA += stepA; spB += stepB;
+    if (remap) {
+      boffA += 16; if (boffA >= G) { boffA -= G; spA += skipA; }
+      boffB += 16; if (boffB >= G) { boffB -= G; spB += skipB; }
+    }
+    ++q_issue; slot_issue = slot_issue == R - 1 ? 0 : slot_issue + 1;
+  };
+
+  f32x16 acc[WIT][WNT];
+#pragma unroll
+  for (int i = 0; i < WIT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposed-read addressing (as in gemm_tn_kernel): 16-lane group gq covers operand rows 16*(gq&1)..+15 and k = 8*(gq>>1)..+7
+  const int gq = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+  const int kq = 8 * (gq >> 1) + lq;
+  const int cbase = 2 * (gq & 1) + (lp >> 1);
+  int offa[WIT][2], offb[WNT][2];  // byte offsets inside a quarter
+#pragma unroll
+  for (int i = 0; i < WIT; ++i) {
+    const int it = wr * WIT + i, si = it >> 2, ch = (it & 3) * 4 + cbase;
+    offa[i][0] = si * 4096 + tr_off(kq, ch) + 8 * (lp & 1); offa[i][1] = si * 4096 + tr_off(kq + 4, ch) + 8 * (lp & 1);
+  }
+#pragma unroll
+  for (int j = 0; j < WNT; ++j) {
+    const int jt = wc * WNT + j, si = NSA + (jt >> 2), ch = (jt & 3) * 4 + cbase;
+    offb[j][0] = si * 4096 + tr_off(kq, ch) + 8 * (lp & 1); offb[j][1] = si * 4096 + tr_off(kq + 4, ch) + 8 * (lp & 1);
+  }
+
+  const int npro = nq < D ? nq : D;
+  for (int q = 0; q < npro; ++q) stage();
+  if (nq >= D) NT8P_WAIT_VM(2 * (D - 1)); else NT8P_WAIT_VM(0);
+  NT8P_BAR();                 // quarter 0 is visible to every wave
+  if (wr == 1) NT8P_BAR();    // the stagger
+  int slot = 0;
+  for (int q = 0; q < nq; ++q) {
+    const char* sq = smem + slot * QB;
+    uint2 fb[WNT][2], fa[WIT][2];
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) { fb[j][0] = ds_read_tr16_b64(sq + offb[j][0]); fb[j][1] = ds_read_tr16_b64(sq + offb[j][1]); }
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) { fa[i][0] = ds_read_tr16_b64(sq + offa[i][0]); fa[i][1] = ds_read_tr16_b64(sq + offa[i][1]); }
+    if (q + D < nq) { stage(); NT8P_WAIT_VM(2 * (D - 1)); }   // quarters q+2 .. q+D stay in flight, q+1 has landed (this wave's part)
+    else NT8P_WAIT_VM(0);
+    NT8P_BAR();
+    NT8P_WAIT_LGKM(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) {
+      const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(fa[i][0].x, fa[i][0].y, fa[i][1].x, fa[i][1].y));
+#pragma unroll
+      for (int j = 0; j < WNT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, make_uint4(fb[j][0].x, fb[j][0].y, fb[j][1].x, fb[j][1].y)), acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    NT8P_BAR();
+    slot = slot == R - 1 ? 0 : slot + 1;
+  }
+  if (wr == 0) NT8P_BAR();
+  // ---- epilogue: 32x32 C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); one register = two 128-B row segments
+  const int col = lane & 31, rb = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < WIT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      const int gn = n0 + wc * (WNT * 32) + j * 32 + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gi = i0 + wr * (WIT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rb;
+        if (gi < g.Ki && gn < g.N) atomicAdd(g.C + (int64_t)gi * g.ldc + gn, acc[i][j][r]);
+      }
+    }
+}
+
+template <int WIT, int WNT>
+static void launch_tn8p(spa3d_ctx* c, TnArgs g, int rounds) {
+  constexpr int TI = 64 * WIT, TNN = 128 * WNT;
+  g.tiles_i = (g.Ki + TI - 1) / TI; g.tiles_n = (g.N + TNN - 1) / TNN;
+  const int64_t tiles = (int64_t)g.tiles_i * g.tiles_n;
+  // M-splits: one workgroup per CU, equal-length splits.  Pick the count that minimises a makespan model:
+  //   rounds on the fullest XCD x (M / s) rows x (time per row at ~4 TF/s per CU)  +  s x (Ki x N x 4 B of f32 atomics at ~1.3 TB/s)
+  int64_t splits;
+  if (rounds > 0) splits = std::max<int64_t>(8, (256 * (int64_t)rounds / tiles) / 8 * 8);
+  else {
+    const double t_row = 2.0 * TI * TNN / 4.0e12, t_atom = (double)g.Ki * g.N * 4.0 / 1.3e12;
+    const int64_t smax = std::max<int64_t>(1, std::min<int64_t>(g.M / 4096, 2048));
+    double best = 1e30; splits = 1;
+    for (int64_t sc = 1; sc <= smax; ++sc) {
+      const int64_t rps_c = ((g.M + sc - 1) / sc + 63) / 64 * 64;
+      const int64_t per_xcd = tiles * ((sc + 7) / 8);  // all tiles of a split run on one XCD (32 CUs), splits are dealt round-robin
+      const double t = (double)((per_xcd + 31) / 32) * (double)rps_c * t_row + (double)sc * t_atom;
+      if (t < best * 0.999) { best = t; splits = sc; }
+    }
+  }
+  splits = std::min<int64_t>(splits, std::max<int64_t>(1, g.M / 4096));
+  int64_t rps = ((g.M + splits - 1) / splits + 63) / 64 * 64;
+  splits = (g.M + rps - 1) / rps;
+  g.splits = (int)splits; g.rows_per_split = rps;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn8p_kernel<WIT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); attr = true; }
+  gemm_tn8p_kernel<WIT, WNT><<<(unsigned)(tiles * ((splits + 7) / 8 * 8)), 512, 163840, c->stream>>>(g);
+}
+
 bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d) {
   // A[m'=i][k'=m] = X[m][i]: sAm == 1, sAk == lda ; B[k'=m][n]: sBn == 1, sBk == ldb ; f32 accumulate
   if (d.sAm != 1 || d.sBn != 1 || !d.out_f32 || !d.accumulate || d.nb1 != 1 || d.nb2 != 1) return false;
@@ -1664,6 +1842,22 @@ bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d) {
   g.M = M; g.Ki = Ki; g.N = N; g.lda = d.sAk; g.ldb = d.sBk; g.ldc = d.sCm;
   g.tiles_i = (Ki + 127) / 128; g.tiles_n = (N + 127) / 128;
   g.brow_group = d.brow_group; g.brow_skip = d.brow_skip;
+  if (c->tn_8p && (M >= 65536 || c->tn_8p == 2) && (g.brow_group == 0 || g.brow_group >= 16)) {
+    // tile shape with the least padding: 384 x 128 / 128 x 384 when one dimension is an odd multiple of 384, else 256 x 256
+    auto waste = [&](int TI, int TNN) { return (double)((Ki + TI - 1) / TI * TI) * ((N + TNN - 1) / TNN * TNN) / ((double)Ki * N); };
+    const double w0 = waste(256, 256), w1 = waste(128, 384), w2 = waste(384, 128);
+    const double wb = std::min(w0, std::min(w1, w2));
+    if (wb <= 1.25 || c->tn_8p == 2) {
+      ProfScope ps(c, PROF_GEMM_TN, 2.0 * (double)M * Ki * N, ((double)M * Ki + (double)M * N) * 2.0);
+      ps.tag(M, N, Ki, 0);
+      const int rounds = c->tn_rounds;
+      if (w0 <= wb * 1.0001) launch_tn8p<4, 2>(c, g, rounds);
+      else if (w1 <= wb * 1.0001) launch_tn8p<2, 3>(c, g, rounds);
+      else launch_tn8p<6, 1>(c, g, rounds);
+      SPA_LAUNCH_CHECK(c);
+      return true;
+    }
+  }
   const int64_t tiles = (int64_t)g.tiles_i * g.tiles_n;
   // enough workgroups to fill 256 CUs several times over, but >= 4096 reduction rows per split so the
   // f32 atomic traffic (4 B per output element per split) stays a few % of the tile's MFMA time

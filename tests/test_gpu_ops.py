@@ -291,6 +291,15 @@ def test_linear_bwd_tiled(lib, M, N, K):
   assert max_abs(dB, rB) < 1e-3 * float(rB.abs().max()) + 1e-4
 
 
+@pytest.mark.parametrize('M,N,K', [(5000, 384, 256), (3333, 2304, 384), (20000, 128, 64), (1100, 600, 1280), (257, 96, 512),
+                                   (9000, 768, 1280), (70001, 384, 768), (4097, 1536, 384), (640, 1280, 1536)])
+def test_linear_bwd_tiled_8phase(lib, monkeypatch, M, N, K):
+  """dB = A^T.dC on the 8-phase TN kernels (256x256 / 128x384 / 384x128 tiles, ring of 16-row quarters), forced for any M"""
+  monkeypatch.setenv('SPA3D_TN_8P', '2')
+  monkeypatch.setenv('SPA3D_NT_8P', '2')
+  test_linear_bwd_tiled(lib, M, N, K)
+
+
 @pytest.mark.parametrize('nseq,S,H,masked', [(5, 25, 8, True), (3, 129, 8, False), (4, 151, 8, True), (2, 128, 8, False), (3, 40, 2, True)])
 def test_attention_fused_fwd_bwd(lib, nseq, S, H, masked):
   """LDS-resident fused forward (impl=2) vs the fp64 oracle; packed q|k|v rows as the QKV projection writes them."""
