@@ -121,6 +121,7 @@ struct spa3d_ctx {
                       // SPA3D_NT_RING=1 ping-pong teams (staggered by one barrier), =3 plain ring; =2 ping-pong forced for small M (tests)
   int nt_256 = 1;     // 256x256 8-wave NT kernel for N % 256 == 0 (SPA3D_NT_256=0 disables; =2 forces small M in tests)
   int nt_occ = 1;     // single-buffer 4-workgroups/CU NT kernel for K <= 512 (SPA3D_NT_OCC=0 disables)
+  bool tn_colsum_fused = false;  // set by gemm_tn_bf16: the last call also produced GemmDesc::colsum_out
   Prof prof;
 };
 
@@ -164,6 +165,8 @@ struct GemmDesc {
   int out_f32 = 0;                   // C is float regardless of T
   int accumulate = 0;                // C += (non-atomic)
   int atomic = 0;                    // C += via atomicAdd (f32 C only)
+  float* colsum_out = nullptr;       // TN (dW) only: also accumulate the column sums of B (bias gradient) when the kernel can;
+                                     // the callee reports it in spa3d_ctx::tn_colsum_fused
   const void* Bt = nullptr;          // optional copy of B stored [N][K] (K contiguous, row stride ldBt) for the tiled kernels
   int64_t ldBt = 0;
   int32_t crow_group = 0, crow_skip = 0;  // C row m is stored at row m + (m/crow_group + 1)*crow_skip (token rows behind a readout row)

@@ -1519,6 +1519,7 @@ struct TnArgs {
   int64_t M; int Ki; int N; int64_t lda, ldb, ldc;
   int tiles_i, tiles_n, splits; int64_t rows_per_split;
   int brow_group, brow_skip;
+  float* colsum;  // 8-phase kernels only: colsum[n] += sum_m B[m][n] (the bias gradient), nullptr = off
 };
 
 __device__ __forceinline__ uint2 ds_read_tr16_b64(const void* p) {
@@ -1755,6 +1756,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs g) {
     offb[j][0] = si * 4096 + tr_off(kq, ch) + 8 * (lp & 1); offb[j][1] = si * 4096 + tr_off(kq + 4, ch) + 8 * (lp & 1);
   }
 
+  // bias gradient on the side: wave-row 0 of the ti == 0 workgroups already holds every B fragment (lane: column lane & 31,
+  // 8 of the quarter's 16 rows); v_dot2c_f32_bf16 against (1, 1) adds two rows per instruction, f32 accumulate
+  const bool do_cs = g.colsum != nullptr && ti == 0 && wr == 0;
+  float cs[WNT];
+#pragma unroll
+  for (int j = 0; j < WNT; ++j) cs[j] = 0.f;
+  const unsigned ones2 = 0x3F803F80u;
   const int npro = nq < D ? nq : D;
   for (int q = 0; q < npro; ++q) stage();
   if (nq >= D) NT8P_WAIT_VM(2 * (D - 1)); else NT8P_WAIT_VM(0);
@@ -1780,11 +1788,28 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs g) {
       for (int j = 0; j < WNT; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, make_uint4(fb[j][0].x, fb[j][0].y, fb[j][1].x, fb[j][1].y)), acc[i][j], 0, 0, 0);
     }
+    if (do_cs) {
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) {
+        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[j]) : "v"(fb[j][0].x), "v"(ones2));
+        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[j]) : "v"(fb[j][0].y), "v"(ones2));
+        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[j]) : "v"(fb[j][1].x), "v"(ones2));
+        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[j]) : "v"(fb[j][1].y), "v"(ones2));
+      }
+    }
     __builtin_amdgcn_s_setprio(0);
     NT8P_BAR();
     slot = slot == R - 1 ? 0 : slot + 1;
   }
   if (wr == 0) NT8P_BAR();
+  if (do_cs) {
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      const float t = cs[j] + __shfl_xor(cs[j], 32, 64);
+      const int gn = n0 + wc * (WNT * 32) + j * 32 + (lane & 31);
+      if (lane < 32 && gn < g.N) atomicAdd(g.colsum + gn, t);
+    }
+  }
   // ---- epilogue: 32x32 C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); one register = two 128-B row segments
   const int col = lane & 31, rb = 4 * (lane >> 5);
 #pragma unroll
@@ -1841,7 +1866,8 @@ bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d) {
   g.A = (const bf16_t*)d.A; g.B = (const bf16_t*)d.B; g.C = (float*)d.C; g.zero = (const bf16_t*)d.zero_page;
   g.M = M; g.Ki = Ki; g.N = N; g.lda = d.sAk; g.ldb = d.sBk; g.ldc = d.sCm;
   g.tiles_i = (Ki + 127) / 128; g.tiles_n = (N + 127) / 128;
-  g.brow_group = d.brow_group; g.brow_skip = d.brow_skip;
+  g.brow_group = d.brow_group; g.brow_skip = d.brow_skip; g.colsum = nullptr;
+  c->tn_colsum_fused = false;
   if (c->tn_8p && (M >= 65536 || c->tn_8p == 2) && (g.brow_group == 0 || g.brow_group >= 16)) {
     // tile shape with the least padding: 384 x 128 / 128 x 384 when one dimension is an odd multiple of 384, else 256 x 256
     auto waste = [&](int TI, int TNN) { return (double)((Ki + TI - 1) / TI * TI) * ((N + TNN - 1) / TNN * TNN) / ((double)Ki * N); };
@@ -1851,6 +1877,7 @@ bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d) {
       ProfScope ps(c, PROF_GEMM_TN, 2.0 * (double)M * Ki * N, ((double)M * Ki + (double)M * N) * 2.0);
       ps.tag(M, N, Ki, 0);
       const int rounds = c->tn_rounds;
+      g.colsum = d.colsum_out; c->tn_colsum_fused = d.colsum_out != nullptr;
       if (w0 <= wb * 1.0001) launch_tn8p<4, 2>(c, g, rounds);
       else if (w1 <= wb * 1.0001) launch_tn8p<2, 3>(c, g, rounds);
       else launch_tn8p<6, 1>(c, g, rounds);

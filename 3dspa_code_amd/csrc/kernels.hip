@@ -663,17 +663,27 @@ template <typename T> void k_broadcast_rows(spa3d_ctx* c, const float* src, int 
   bcast_rows_kernel<T><<<GRID1D((int64_t)rows * d * B, 256), 256, 0, c->stream>>>(src, (int64_t)rows * d, dst, B); SPA_LAUNCH_CHECK(c);
 }
 template <typename T>
-__global__ void bcast_grad_kernel(const T* __restrict__ dsrc, int64_t per, int64_t B, int64_t bstride, float* __restrict__ dparam) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int64_t b = 0; b < B; ++b) s += ld(dsrc + b * bstride + i);
-    dparam[i] += s;
+__global__ void bcast_grad_kernel(const T* __restrict__ dsrc, int64_t per, int64_t B, int64_t bstride, float* __restrict__ dparam, int64_t bchunk) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per) return;
+  const int64_t b0 = (int64_t)blockIdx.y * bchunk; int64_t b1 = b0 + bchunk; if (b1 > B) b1 = B;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains: the strided rows are latency, not bandwidth
+  int64_t b = b0;
+  for (; b + 3 < b1; b += 4) {
+    s0 += ld(dsrc + b * bstride + i); s1 += ld(dsrc + (b + 1) * bstride + i);
+    s2 += ld(dsrc + (b + 2) * bstride + i); s3 += ld(dsrc + (b + 3) * bstride + i);
   }
+  for (; b < b1; ++b) s0 += ld(dsrc + b * bstride + i);
+  const float s = (s0 + s1) + (s2 + s3);
+  if (gridDim.y == 1) dparam[i] += s; else atomicAdd(dparam + i, s);
 }
-// dparam[per] += sum_b dsrc[b*bstride + :per]
+// dparam[per] += sum_b dsrc[b*bstride + :per]   (B up to ~10^5 strided rows: split over blockIdx.y, one f32 atomic per column per slice)
 template <typename T> void k_bcast_grad(spa3d_ctx* c, const T* dsrc, int64_t per, int64_t B, int64_t bstride, float* dparam) {
   if (c->dry || B == 0) return;
-  bcast_grad_kernel<T><<<GRID1D(per, 256), 256, 0, c->stream>>>(dsrc, per, B, bstride, dparam); SPA_LAUNCH_CHECK(c);
+  const int64_t gx = cdiv(per, 256);
+  int64_t gy = std::max<int64_t>(1, std::min<int64_t>(B / 32, std::max<int64_t>(1, 2048 / gx)));
+  const int64_t bchunk = cdiv(B, gy); gy = cdiv(B, bchunk);
+  bcast_grad_kernel<T><<<dim3((unsigned)gx, (unsigned)gy), 256, 0, c->stream>>>(dsrc, per, B, bstride, dparam, bchunk); SPA_LAUNCH_CHECK(c);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -235,9 +235,11 @@ template <typename T> struct Net {
       d.A = X; d.B = dY + (int64_t)s * l.segw; d.C = l.gw[s]; d.M = l.K; d.N = l.segw; d.K = M;
       d.sAm = 1; d.sAk = ldx ? ldx : l.K; d.sBk = l.N; d.sBn = 1; d.sCm = l.segw;
       d.out_f32 = 1; d.accumulate = 1; d.zero_page = zero_page; d.brow_group = brow_group; d.brow_skip = brow_skip;
+      d.colsum_out = l.gb ? l.gb + (int64_t)s * l.segw : nullptr;  // bias gradient rides along in the 8-phase dW kernel
+      c->tn_colsum_fused = false;
       gemm(d);
+      if (l.gb && !c->tn_colsum_fused) k_colsum<T>(c, dY + (int64_t)s * l.segw, M, l.segw, l.N, l.gb + (int64_t)s * l.segw, brow_group, brow_skip);
     }
-    if (l.gb) k_colsum<T>(c, dY, M, l.N, l.N, l.gb, brow_group, brow_skip);
   }
 
   // ------------------------------------------------------------------ attention core (attention.hip)
