@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libspa3d_hip.so')
 SOURCES = ['kernels.hip', 'gemm_generic.hip', 'gemm_fast.hip', 'attention.hip', 'attention_fused.hip', 'ops.hip', 'samplers.hip', 'model.hip']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function', '-Wno-inline-asm',
          '-Wno-unused-variable', '-Wno-unused-but-set-variable']
 
 

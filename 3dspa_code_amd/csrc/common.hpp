@@ -117,6 +117,8 @@ struct spa3d_ctx {
   int nt_8p = 1;      // 8-phase kernels (256x256 / 128x384, counted vmcnt, staggered wave rows); 2 = also for small M, 0/3 = off
   int tn_8p = 1;      // 8-phase TN (dW) kernels; SPA3D_TN_8P=0 disables, =2 forces (tests)
   int tn_rounds = 0;  // 0: M-split count of the 8-phase TN kernels from the makespan model; > 0: 256 * rounds / tiles (experiments)
+  int nt_8pp = 1;     // persistent form of the 256x256 8-phase NT kernel (SPA3D_NT_8PP=0 disables): +3-6 %
+  int nt_stream = 1;  // non-temporal stores for bf16 GEMM outputs >= 512 MB (SPA3D_NT_STREAM=0 disables)
   int nt_ring = 0;    // persistent 256x128 kernels, measured SLOWER than the 128x128 ones (500-740 vs 660-885 TF/s), off:
                       // SPA3D_NT_RING=1 ping-pong teams (staggered by one barrier), =3 plain ring; =2 ping-pong forced for small M (tests)
   int nt_256 = 1;     // 256x256 8-wave NT kernel for N % 256 == 0 (SPA3D_NT_256=0 disables; =2 forces small M in tests)

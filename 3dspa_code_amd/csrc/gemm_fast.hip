@@ -25,12 +25,20 @@ typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
 #define GLDS16(gptr, lptr) \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
+// LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit lane offset: keeps per-lane addressing at one VGPR per load
+// (the builtin form is free to widen the offsets to 64 bits, which in the persistent kernel spilled them into the K-loop)
+__device__ __forceinline__ void glds16_s(const void* base_uniform, unsigned off, const void* lds_dst) {
+  const unsigned l = (unsigned)(uintptr_t)lds_dst;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base_uniform), "s"(l) : "memory", "m0");
+}
+
 struct NtArgs {
   const bf16_t* A; const bf16_t* Bt; void* C;
   int64_t M; int N; int K; int64_t lda, ldb, ldc;
   const float* bias; const bf16_t* aux; bf16_t* pre_out; int epi; int out_f32; int accumulate; float alpha;
   int tiles_m, tiles_n, crow_group, crow_skip;
   int dbg;  // experiments only (SPA3D_NT_DBG): 1 = skip the epilogue stores
+  int nt_store;  // bf16 output with non-temporal stores: a streamed output far larger than the caches (+3-6 % measured at K = 384)
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
@@ -1146,10 +1154,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(NtArgs g) {
 //   one barrier behind, so on every SIMD one wave is in its MFMA section while the other is in its read/stage section.
 // =================================================================================================================
 // 8 consecutive columns of one output row: alpha/bias, optional pre-activation copy, GELU, residual / GELU-gradient, store.
-template <bool AUXPRE = false>
+template <bool AUXPRE = false, bool REMAP = true>
 __device__ __forceinline__ void nt_store8(const NtArgs& g, int64_t gm, int gn, float (&v)[8], const float (&b8)[8], uint4 auxpre = uint4{0, 0, 0, 0}) {
   int64_t crow = gm;
-  if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
+  if (REMAP && g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = g.alpha * v[r] + b8[r];
   const int64_t ci = crow * g.ldc + gn;
@@ -1185,7 +1193,8 @@ __device__ __forceinline__ void nt_store8(const NtArgs& g, int64_t gm, int gn, f
     uint4 o4; unsigned* op = (unsigned*)&o4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) op[r] = (unsigned)f2bf(v[2 * r]) | ((unsigned)f2bf(v[2 * r + 1]) << 16);
-    *cp = o4;
+    if (g.nt_store) { typedef __attribute__((ext_vector_type(4))) unsigned u32x4; __builtin_nontemporal_store(u32x4{o4.x, o4.y, o4.z, o4.w}, (u32x4*)cp); }
+    else *cp = o4;
   }
 }
 
@@ -1415,6 +1424,195 @@ static void launch_nt8p(spa3d_ctx* c, const NtArgs& g) {
   gemm_nt8p_kernel<WMT, WNT><<<(unsigned)b2, 512, LDS, c->stream>>>(g2);
 }
 
+// =================================================================================================================
+// Persistent form of the 256x256 8-phase kernel: one workgroup per CU walks its XCD's tile list (stride 32).  What it removes
+// from every tile: the dispatch, the prologue's load latency and the store drain.  After a tile's K-loop the first two K-tiles of
+// the NEXT tile are issued (A ring slots 0 and 1, both B buffers); the epilogue then runs out of ring slot 2 (4 KiB per wave,
+// one 16-row accumulator row per pass), and the next K-loop starts behind a COUNTED wait: vmcnt retires in issue order and counts
+// stores too (MI355X_MICROARCH.md "s_waitcnt vmcnt(N)"), so "all but the second K-tile's loads and this epilogue's stores" means
+// the first K-tile has landed while the stores are still draining.  Edge tiles (rows past M) skip stores, so they drain to 0.
+// =================================================================================================================
+__global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
+  constexpr int WMT = 8, WNT = 4, BM = 256, BN = 256, NA = 2, NB = 2, HM = 4, HN = 2;
+  constexpr int ASLOT = BM * 128, BBUF = BN * 128, BOFF = 3 * ASLOT, NKT = 2 * NA + 2 * NB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int xcd = blockIdx.x & 7, cu_slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+  const int per_xcd = ((g.tiles_m + 7) / 8) * g.tiles_n;  // tile list of one XCD (entries with tm >= tiles_m are skipped)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sr = lane >> 3, scp = lane & 7;
+  const int sc = (scp ^ sr) * 8;
+  const int nt = g.K / 64;  // >= 2 (host)
+  auto next_valid = [&](int idx) { while (idx < per_xcd && (idx / g.tiles_n) * 8 + xcd >= g.tiles_m) idx += nslot; return idx; };
+  // addresses = per-tile uniform base (SGPRs) + 32-bit lane offsets (rows are clamped per tile on the M edge only): four VGPRs per
+  // operand instead of eight 64-bit pointers, and the K-tile advance is a scalar add
+  // One lane-offset VGPR per operand: (row-in-group * ld + swizzled column) * 2.  The 8-row group of each LDS-DMA is wave-uniform and
+  // goes into the scalar base; on the M edge the GROUP is clamped (M % 8 == 0 on the host: a group is valid or invalid as a whole, and
+  // an invalid one only feeds accumulator rows that are never stored).
+  int rga[1][2][NA], rgb[1][2][NB];  // row groups (uniform)
+#pragma unroll
+  for (int v = 0; v < 1; ++v) {
+    const int vw = w;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) { const int gi = i * 8 + vw; rga[v][h][i] = (gi / WMT) * (WMT * 16) + h * (WMT * 8) + (gi % WMT) * 8; }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) { const int gi = i * 8 + vw; rgb[v][h][i] = (gi / WNT) * (WNT * 16) + h * (WNT * 8) + (gi % WNT) * 8; }
+    }
+  }
+  const unsigned oal = (unsigned)(sr * g.lda + sc) * 2u, obl = (unsigned)(sr * g.ldb + sc) * 2u;
+  const int64_t lda2 = g.lda * 2, ldb2 = g.ldb * 2;
+  const char* baseA = nullptr; const char* baseB = nullptr;
+  int maxgrp = 0;
+  auto set_tile = [&](int64_t m0, int n0) {
+    baseA = (const char*)(g.A + m0 * g.lda); baseB = (const char*)(g.Bt + (int64_t)n0 * g.ldb);
+    const int64_t mg = g.M - 8 - m0; maxgrp = mg > 255 ? 255 : (mg < 0 ? 0 : (int)mg);
+  };
+  auto stageA = [&](int kt, int slot) {
+    char* base = smem + slot * ASLOT;
+    const char* src = baseA + kt * 128;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < NA; ++i) { const int rg = rga[0][h][i] < maxgrp ? rga[0][h][i] : maxgrp; glds16_s(src + rg * lda2, oal, base + rga[0][h][i] * 128); }
+  };
+  auto stageB = [&](int h, int kt) {
+    char* base = smem + (kt & 1) * BBUF + BOFF;
+    const char* src = baseB + kt * 128;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) glds16_s(src + rgb[0][h][i] * ldb2, obl, base + rgb[0][h][i] * 128);
+  };
+  auto prologue = [&]() { stageA(0, 0); stageB(0, 0); stageB(1, 0); stageA(1, 1); stageB(0, 1); stageB(1, 1); };
+
+  int idx = next_valid(cu_slot);
+  if (idx >= per_xcd) return;
+  int64_t m0 = (int64_t)((idx / g.tiles_n) * 8 + xcd) * BM; int n0 = (idx % g.tiles_n) * BN;
+  set_tile(m0, n0);
+  prologue();
+  NT8P_WAIT_VM(NKT);
+  const int a_off = (wr * WMT * 16 + fr) * 128, b_off = BOFF + (wc * WNT * 16 + fr) * 128;
+  const int x0 = ((fq) ^ (fr & 7)) * 16, x1 = ((4 + fq) ^ (fr & 7)) * 16;
+  const int nst_code = (g.pre_out || g.out_f32) ? 1 : 0;  // 32 or 16 stores per wave per tile
+
+  while (true) {
+    NT8P_BAR();                 // K-tile 0 is visible to every wave; every wave has left the previous epilogue
+    if (wr == 1) NT8P_BAR();    // the stagger
+    f32x4 acc[WMT][WNT];
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 aq[HM][2], bq0[HN][2], bq1[HN][2];
+#define NT8P_MFMA(AI, BJ, BQ)                                                                                                         \
+  __builtin_amdgcn_s_setprio(1);                                                                                                      \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < HM; ++i) _Pragma("unroll") for (int j = 0; j < HN; ++j) \
+      acc[(AI) + i][(BJ) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BQ[j][ks], aq[i][ks], acc[(AI) + i][(BJ) + j], 0, 0, 0);       \
+  __builtin_amdgcn_s_setprio(0);
+    int aslot = 0, aslot2 = 2;
+    for (int t = 0; t < nt; ++t) {
+      const char* sa = smem + aslot * ASLOT;
+      const char* sb = smem + (t & 1) * BBUF;
+#pragma unroll
+      for (int j = 0; j < HN; ++j) { bq0[j][0] = *(const bf16x8*)(sb + b_off + j * 2048 + x0); bq0[j][1] = *(const bf16x8*)(sb + b_off + j * 2048 + x1); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < HM; ++i) { aq[i][0] = *(const bf16x8*)(sa + a_off + i * 2048 + x0); aq[i][1] = *(const bf16x8*)(sa + a_off + i * 2048 + x1); }
+      if (t + 2 < nt) stageA(t + 2, aslot2);
+      NT8P_WAIT_LGKM(2 * HM);
+      NT8P_BAR();
+      NT8P_WAIT_LGKM(0);
+      NT8P_MFMA(0, 0, bq0)
+      NT8P_BAR();
+#pragma unroll
+      for (int j = 0; j < HN; ++j) { bq1[j][0] = *(const bf16x8*)(sb + b_off + (HN + j) * 2048 + x0); bq1[j][1] = *(const bf16x8*)(sb + b_off + (HN + j) * 2048 + x1); }
+      if (t + 2 < nt) stageB(0, t + 2);
+      NT8P_BAR();
+      NT8P_WAIT_LGKM(0);
+      NT8P_MFMA(0, HN, bq1)
+      NT8P_BAR();
+#pragma unroll
+      for (int i = 0; i < HM; ++i) { aq[i][0] = *(const bf16x8*)(sa + a_off + (HM + i) * 2048 + x0); aq[i][1] = *(const bf16x8*)(sa + a_off + (HM + i) * 2048 + x1); }
+      NT8P_BAR();
+      NT8P_WAIT_LGKM(0);
+      NT8P_MFMA(HM, HN, bq1)
+      NT8P_BAR();
+      if (t + 2 < nt) { stageB(1, t + 2); NT8P_WAIT_VM(NKT); }
+      else NT8P_WAIT_VM(0);
+      NT8P_BAR();
+      NT8P_MFMA(HM, 0, bq0)
+      NT8P_BAR();
+      aslot = aslot == 2 ? 0 : aslot + 1; aslot2 = aslot2 == 2 ? 0 : aslot2 + 1;
+    }
+#undef NT8P_MFMA
+    if (wr == 0) NT8P_BAR();  // pairs with wave-row 1's extra barrier: every LDS read of this tile is done
+
+    // ---- residual / pre-activation operand of this tile first (its data is needed first), then the next tile's two K-tiles
+    const int64_t cm0 = m0; const int cn0 = n0;
+    const bool interior = cm0 + BM <= g.M;
+    const int r8 = lane >> 3, c8 = lane & 7;
+    const int gn = cn0 + wc * 64 + c8 * 8;
+    int rowl = wr * 128 + r8;
+    asm volatile("" : "+v"(rowl));  // opaque per tile: otherwise sixteen 64-bit row addresses are hoisted out of the tile loop and spilled
+    uint4 auxv[4][2];  // four passes' worth at a time (all sixteen would spill)
+    auto load_aux = [&](int i0_) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int64_t gm = cm0 + (rowl + (i0_ + i) * 16 + it * 8);
+          auxv[i][it] = uint4{0, 0, 0, 0};
+          if (gm < g.M) auxv[i][it] = *(const uint4*)(g.aux + gm * g.ldc + gn);  // no output-row remap in this kernel (host)
+        }
+    };
+    if (g.aux) load_aux(0);
+    idx = next_valid(idx + nslot);
+    const bool more = idx < per_xcd;
+    if (more) {
+      m0 = (int64_t)((idx / g.tiles_n) * 8 + xcd) * BM; n0 = (idx % g.tiles_n) * BN;
+      set_tile(m0, n0);
+      prologue();
+    }
+    // ---- epilogue out of ring slot 2: wave-private [16 rows][16 chunks of 16 B] f32, chunk ^= row (conflict-free both ways)
+    char* reg = smem + 2 * ASLOT + w * 4096;
+    float b8[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) b8[r] = 0.f;
+    if (g.bias) { const float4 b0 = *(const float4*)(g.bias + gn), b1 = *(const float4*)(g.bias + gn + 4);
+      b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w; }
+#pragma unroll
+    for (int i = 0; i < WMT; ++i) {
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) *(f32x4*)(reg + fr * 256 + (((j * 4 + fq) ^ fr) << 4)) = acc[i][j];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = it * 8 + r8;
+        const f32x4 v0 = *(const f32x4*)(reg + row * 256 + (((2 * c8) ^ row) << 4));
+        const f32x4 v1 = *(const f32x4*)(reg + row * 256 + (((2 * c8 + 1) ^ row) << 4));
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const int64_t gm = cm0 + (rowl + i * 16 + it * 8);
+        if (gm < g.M) nt_store8<true, false>(g, gm, gn, v, b8, auxv[i & 3][it]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (i == 3 && g.aux) load_aux(4);
+    }
+    // every path consumes the aux registers here: otherwise the compiler's waitcnt pass carries "load possibly pending" to the
+    // K-loop header (it cannot correlate the load and use predicates) and drains vmcnt INSIDE the K-loop, LDS-DMA included
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) asm volatile("" ::"v"(auxv[i][it].x), "v"(auxv[i][it].y), "v"(auxv[i][it].z), "v"(auxv[i][it].w));
+    if (!more) break;
+    // the next tile's first K-tile has landed when only its second K-tile and this epilogue's stores can still be outstanding
+    if (!interior) NT8P_WAIT_VM(0);
+    else if (nst_code) NT8P_WAIT_VM(NKT + 32);
+    else NT8P_WAIT_VM(NKT + 16);
+  }
+}
+
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
@@ -1437,6 +1635,7 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   g.tiles_m = (int)((d.M + 127) / 128); g.tiles_n = (d.N + 127) / 128;
   g.crow_group = d.crow_group; g.crow_skip = d.crow_skip;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SPA3D_NT_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
+  g.nt_store = (!d.out_f32 && (double)d.M * d.N * 2.0 >= 512e6 && c->nt_stream) ? 1 : 0;
   const int64_t blocks = (int64_t)((g.tiles_m + 7) / 8) * 8 * g.tiles_n;
   if (blocks > 0x7fffffffLL) return false;
   static bool attr_set = false;
@@ -1457,7 +1656,12 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   }
   // 8-phase kernels: 256x256 when 256 | N, 128x384 when 384 | N (see the kernel header for the measurements)
   if (c->nt_8p && (d.N % 256 == 0 || d.N % 384 == 0) && (d.M >= 256 * 64 || c->nt_8p == 2) && c->nt_8p != 3) {
-    if (d.N % 256 == 0) launch_nt8p<8, 4>(c, g); else launch_nt8p<4, 6>(c, g);
+    if (d.N % 256 == 0 && c->nt_8pp && d.K >= 128 && !d.accumulate && d.crow_group == 0 && d.M % 8 == 0) {  // persistent form (accumulate would add loads to the counted wait)
+      NtArgs g2 = g; g2.tiles_m = (int)((g.M + 255) / 256); g2.tiles_n = g.N / 256;
+      static bool attrp = false;
+      if (!attrp) { (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); attrp = true; }
+      gemm_nt8pp_kernel<<<256, 512, 163840, c->stream>>>(g2);
+    } else if (d.N % 256 == 0) launch_nt8p<8, 4>(c, g); else launch_nt8p<4, 6>(c, g);
     SPA_LAUNCH_CHECK(c);
     return true;
   }

@@ -244,6 +244,7 @@ def test_cfg1_bf16_forced_8phase_kernels_vs_generic(spa3d, monkeypatch):
   gb['depth_features'] = gb['depth_features'].bfloat16()
   noise = _noise(B, cfg).cuda()
   monkeypatch.setenv('SPA3D_NT_8P', '2')
+  monkeypatch.setenv('SPA3D_NT_8PP', '1')
   monkeypatch.setenv('SPA3D_TN_8P', '2')
   m_8p = product_model(spa3d, cfg, 'bf16')
   params = m_8p.init(0, gb)['params']
@@ -251,6 +252,7 @@ def test_cfg1_bf16_forced_8phase_kernels_vs_generic(spa3d, monkeypatch):
   ld_f, g_f, p_f = m_8p.loss_and_grads({'params': params}, gb, noise=noise, return_predictions=True)
   g_fast = g_f.flat.clone()
   monkeypatch.delenv('SPA3D_NT_8P')
+  monkeypatch.delenv('SPA3D_NT_8PP')
   monkeypatch.delenv('SPA3D_TN_8P')
   monkeypatch.setenv('SPA3D_GEMM_IMPL', '1')
   monkeypatch.setenv('SPA3D_ATTN_IMPL', '1')

@@ -390,6 +390,17 @@ def test_linear_tiled_nt_8phase(lib, monkeypatch, M, N, K, act, res, bias):
   test_linear_tiled_nt(lib, M, N, K, act, res, bias)
 
 
+@pytest.mark.parametrize('M,N,K,act,res,bias', [(70001, 512, 256, 0, True, True), (70008, 512, 256, 0, True, True), (140000, 256, 128, 1, False, True), (66000, 768, 384, 0, False, False),
+                                                (4133, 2304, 384, 0, True, False), (256 * 300, 512, 192, 0, True, True), (9000, 1280, 768, 1, False, True)])
+def test_linear_tiled_nt_8phase_persistent(lib, monkeypatch, M, N, K, act, res, bias):
+  """persistent 256x256 8-phase kernel (SPA3D_NT_8PP=1): more tiles than CUs (cross-tile prefetch + counted store wait), ragged
+  last M tile (drain path), exact multiples, residual / GELU epilogues"""
+  monkeypatch.setenv('SPA3D_NT_RING', '0')
+  monkeypatch.setenv('SPA3D_NT_8P', '2')
+  monkeypatch.setenv('SPA3D_NT_8PP', '1')
+  test_linear_tiled_nt(lib, M, N, K, act, res, bias)
+
+
 @pytest.mark.parametrize('M,N,K,act,res,bias', [(4133, 2304, 384, 0, False, False), (1000, 1536, 384, 1, False, True),
                                                 (2050, 768, 256, 0, True, True), (700, 1280, 1536, 0, False, True), (300, 256, 64, 0, False, False)])
 def test_linear_tiled_nt_256(lib, monkeypatch, M, N, K, act, res, bias):
