@@ -1640,7 +1640,9 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   if (blocks > 0x7fffffffLL) return false;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
-  ProfScope ps(c, PROF_GEMM_NT, 2.0 * (double)d.M * d.N * d.K, ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * 2.0);
+  // algorithmic bytes: A, B, C once, plus the residual / pre-activation operand read and the second (pre-activation) output
+  ProfScope ps(c, PROF_GEMM_NT, 2.0 * (double)d.M * d.N * d.K,
+               ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N * (d.out_f32 ? 2.0 : 1.0) * (d.accumulate ? 2.0 : 1.0) + (double)d.M * d.N * ((d.aux ? 1.0 : 0.0) + (d.pre_out ? 1.0 : 0.0))) * 2.0);
   ps.tag(d.M, d.N, d.K, d.epi | (d.aux ? 4 : 0) | (d.pre_out ? 8 : 0) | (d.out_f32 ? 16 : 0) | (d.accumulate ? 32 : 0) | (d.crow_group ? 64 : 0) | (d.sAm != d.K ? 128 : 0));
   const int KT = d.K / 64;
   if (c->nt_ring && d.N % 128 == 0 && d.N <= 4096 && (d.M >= 256 * 512 || c->nt_ring == 2 || c->nt_ring == 4)) {

@@ -62,6 +62,28 @@ def synth_batch(B, N, Q, T, dino_dim, depth_dim, device, seed):
   return batch
 
 
+def pmc_traffic(kernel_class: str, launches_per_step: float):
+  """HBM traffic per launch of the dominant kernel class from the committed rocprofv3 --pmc passes of this same command
+  (profiles/r01_bench_b64_pmc_{fetch,write}.csv: separate passes, KiB units, FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM").
+  Returns (bytes_per_launch, source) or (None, None) when the summaries are absent or the class is unknown."""
+  import csv
+  prefix = {'gemm_nt_bf16': 'gemm_nt', 'gemm_tn_bf16': 'gemm_tn', 'attention_fused_bwd': 'attn_bwd', 'attention_fused_fwd': 'attn_fwd',
+            'gemm_generic': 'gemm_generic'}.get(kernel_class.split(' ')[0])
+  f_fetch = os.path.join(ROOT, 'profiles', 'r01_bench_b64_pmc_fetch.csv'); f_write = os.path.join(ROOT, 'profiles', 'r01_bench_b64_pmc_write.csv')
+  if prefix is None or not (os.path.exists(f_fetch) and os.path.exists(f_write)):
+    return None, None
+  def total(path, counter):
+    t, n = 0.0, 0
+    for r in csv.DictReader(open(path)):
+      if r['counter'] == counter and r['kernel'].startswith(prefix):
+        t += float(r['total']); n += int(r['dispatches'])
+    return t, n
+  fetch, n = total(f_fetch, 'FETCH_SIZE'); write, _ = total(f_write, 'WRITE_SIZE')
+  if n == 0:
+    return None, None
+  return (2.0 * fetch + write) * 1024.0 / n, 'profiles/r01_bench_b64_pmc_fetch.csv + _write.csv (rocprofv3 --pmc, bench.py --steps 1 --warmup 0)'
+
+
 def cpu_baseline():
   """The CPU restatement of the reference graph (oracle, kind "port") timed on this host: BASELINE.json configs[0]
   (B=2, 64+16 tracks, T=24, xyz-only, fp32), one fwd+bwd step.  The reference's own JAX path cannot run here
@@ -143,6 +165,9 @@ def main():
   if prof:
     roof = spa3d.profile_summary(model, h)
     lib.spa3d_prof_enable(h, 0)
+    if roof is not None:
+      roof['traffic'], roof['traffic_source'] = pmc_traffic(roof['kernel'], roof['launches'] / max(1, args.steps))
+      roof['algorithmic_bytes_per_launch'] = next(c['bytes'] / max(1, c['launches']) for c in roof['classes'] if c['kernel'] == roof['kernel'])
   tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
   if world > 1:
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
