@@ -16,6 +16,7 @@
 //                                                             row-major LDS image with ds_read_b64_tr_b16 using the same k order.
 //   lane ends with 4 consecutive d of one query -> 8-byte stores.
 #include "common.hpp"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -36,6 +37,21 @@ __device__ __forceinline__ uint2 lds_tr16_b64(const void* p) {
   const unsigned a = (unsigned)(uintptr_t)p;
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a) : "memory");
   return v;
+}
+
+// the same read with a compile-time byte offset in the instruction: without it every distinct address is a loop-invariant VGPR
+// (the 8-wave backward spilled ~60 of them)
+template <int OFF>
+__device__ __forceinline__ uint2 lds_tr16_b64_o(const void* p) {
+  static_assert(OFF >= 0 && OFF < 65536, "16-bit DS offset");
+  uint2 v;
+  const unsigned a = (unsigned)(uintptr_t)p;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+  return v;
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
 constexpr int DH = 96, ROWB = DH * 2;  // 192-byte LDS rows
@@ -550,6 +566,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
   char* Qs = smem; char* Ks = Qs + S_pad * ROWB; char* Vs = Ks + S_pad * ROWB; char* dOs = Vs + S_pad * ROWB;
   float* kbias = (float*)(dOs + S_pad * ROWB); float* mrow = kbias + S_pad; float* lrow = mrow + S_pad; float* drow = lrow + S_pad;
   float* sred = drow + S_pad;  // [2][96] scale-gradient staging
+  float* sscale = sred + 2 * DH;  // [2][96] RMSNorm scales (LDS copies: as loop invariants in registers they cost 48 VGPRs)
   const int S = g.S, E = g.H * DH;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, role = wv >> 2, w = wv & 3, fr = lane & 15, fq = lane >> 4;
   const int tq = fr >> 2, tp = fr & 3;
@@ -561,6 +578,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) ds_acc[i][r] = 0.f;
 
+  for (int t = tid; t < 2 * DH; t += 512) sscale[t] = t < DH ? g.sq[t] : g.sk[t - DH];  // visible after the first problem's barrier
   for (int64_t prob = blockIdx.x; prob < g.nprob; prob += gridDim.x) {
     const int64_t seq = prob / g.H; const int h = (int)(prob - seq * g.H);
     __syncthreads();  // previous problem's LDS reads are done
@@ -660,13 +678,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
       }
       // dQ^^T[d][q] = sum_keys K^^T[d][key] dS^T[key][q]  (already times alpha)
       f32x4 dqa[6];
-#pragma unroll
-      for (int dt = 0; dt < 6; ++dt) {
+      const char* kbase = Ks + tp * 8 + (4 * fq + tq) * ROWB;
+      static_for<0, 6>([&](auto dtc) {
+        constexpr int dt = decltype(dtc)::value;
         dqa[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         uint2 lo[KT / 2], hi[KT / 2];
-        const char* base = Ks + (dt * 16 + tp * 4) * 2 + (4 * fq + tq) * ROWB;
-#pragma unroll
-        for (int s2 = 0; s2 < KT / 2; ++s2) { lo[s2] = lds_tr16_b64(base + (32 * s2) * ROWB); hi[s2] = lds_tr16_b64(base + (32 * s2 + 16) * ROWB); }
+        static_for<0, KT / 2>([&](auto sc_) {
+          constexpr int s2 = decltype(sc_)::value;
+          lo[s2] = lds_tr16_b64_o<dt * 32 + 32 * s2 * ROWB>(kbase); hi[s2] = lds_tr16_b64_o<dt * 32 + (32 * s2 + 16) * ROWB>(kbase);
+        });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -674,7 +694,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
           const uint4 u = make_uint4(lo[s2].x, lo[s2].y, hi[s2].x, hi[s2].y);
           dqa[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, u), dsb[s2], dqa[dt], 0, 0, 0);
         }
-      }
+      });
       // RMSNorm backward for query fr: lane holds d = 16dt + 4fq + r
       float x[6][4]; float ss = 0.f;
 #pragma unroll
@@ -688,7 +708,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
       float gx = 0.f;
 #pragma unroll
       for (int dt = 0; dt < 6; ++dt) {
-        const f32x4 sc = *(const f32x4*)(g.sq + dt * 16 + fq * 4);
+        const f32x4 sc = *(const f32x4*)(sscale + dt * 16 + fq * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { x[dt][r] *= rr; gx += dqa[dt][r] * sc[r] * x[dt][r]; }
       }
@@ -698,7 +718,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
         bf16_t* op = g.dq + (seq * S + qrow) * g.ldq + h * DH + fq * 4;
 #pragma unroll
         for (int dt = 0; dt < 6; ++dt) {
-          const f32x4 sc = *(const f32x4*)(g.sq + dt * 16 + fq * 4);
+          const f32x4 sc = *(const f32x4*)(sscale + dt * 16 + fq * 4);
           u16x4 o4;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -759,11 +779,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
         // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^^T[d][key] += Q^^T[d][q] dS[q][key]
         uint2 olo[6], ohi[6], qlo[6], qhi[6];
         const int roff = (32 * s2 + 4 * fq + tq) * ROWB + tp * 8;
-#pragma unroll
-        for (int dt = 0; dt < 6; ++dt) {
-          olo[dt] = lds_tr16_b64(dOs + roff + dt * 32); ohi[dt] = lds_tr16_b64(dOs + roff + 16 * ROWB + dt * 32);
-          qlo[dt] = lds_tr16_b64(Qs + roff + dt * 32); qhi[dt] = lds_tr16_b64(Qs + roff + 16 * ROWB + dt * 32);
-        }
+        const char* ob = dOs + roff; const char* qb_ = Qs + roff;
+        static_for<0, 6>([&](auto dtc) {
+          constexpr int dt = decltype(dtc)::value;
+          olo[dt] = lds_tr16_b64_o<dt * 32>(ob); ohi[dt] = lds_tr16_b64_o<16 * ROWB + dt * 32>(ob);
+          qlo[dt] = lds_tr16_b64_o<dt * 32>(qb_); qhi[dt] = lds_tr16_b64_o<16 * ROWB + dt * 32>(qb_);
+        });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -787,7 +808,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
       float gx = 0.f;
 #pragma unroll
       for (int dt = 0; dt < 6; ++dt) {
-        const f32x4 sc = *(const f32x4*)(g.sk + dt * 16 + fq * 4);
+        const f32x4 sc = *(const f32x4*)(sscale + DH + dt * 16 + fq * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { x[dt][r] *= rr; gx += dka[dt][r] * sc[r] * x[dt][r]; }
       }
@@ -798,7 +819,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
         bf16_t* ovp = g.dv + (seq * S + krow) * g.ldv + h * DH + fq * 4;
 #pragma unroll
         for (int dt = 0; dt < 6; ++dt) {
-          const f32x4 sc = *(const f32x4*)(g.sk + dt * 16 + fq * 4);
+          const f32x4 sc = *(const f32x4*)(sscale + DH + dt * 16 + fq * 4);
           u16x4 k4, v4;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -832,7 +853,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
 
 template <int KT>
 static void launch_bwd(spa3d_ctx* c, const AttnBwdArgs& a) {
-  const int lds = 4 * KT * 16 * ROWB + 4 * KT * 16 * 4 + 2 * DH * 4;
+  const int lds = 4 * KT * 16 * ROWB + 4 * KT * 16 * 4 + 4 * DH * 4;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)attn_bwd8_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
