@@ -214,6 +214,11 @@ template <typename T> void k_scatter_rows(spa3d_ctx*, const T* src, T* dst, int6
 template <typename T> void k_compact_tokens(spa3d_ctx*, const T* tok, T* dst, int64_t nseq, int S, int d);
 template <typename T> void k_broadcast_rows(spa3d_ctx*, const float* src, int rows, int d, T* dst, int64_t B);
 template <typename T> void k_bcast_grad(spa3d_ctx*, const T* dsrc, int64_t per, int64_t B, int64_t bstride, float* dparam);
+// Dense with input width K <= 4 as streaming kernels (false: shape not covered, use the GEMM path)
+template <typename T> bool k_rank_fwd(spa3d_ctx*, const T* x, const T* w /*[K][N]*/, const float* bias, T* out /*+=*/, int64_t M, int N, int K, int64_t ldo,
+                                      int rgroup, int rskip);
+template <typename T> bool k_rank_bwd(spa3d_ctx*, const T* x, const T* dy, int64_t M, int N, int K, int64_t ldy, int rgroup, int rskip, float* gw /*+=*/,
+                                      float* gb /*+=, may be null*/);
 void k_discretize(spa3d_ctx*, const float* lat, const float* noise, int discretize, float* out, float* clipmask, int64_t n);
 void k_query_embed1(spa3d_ctx*, const float* qp, int64_t nq, int nf, float track_scale, float time_scale, float* feat, int32_t* qframe,
                     int NC = 3);

@@ -186,6 +186,7 @@ void gemm_generic(spa3d_ctx* c, const GemmDesc& d) {
   }
   ProfScope ps(c, PROF_GEMM_GENERIC, 2.0 * (double)d.M * d.N * d.K * (double)nbatch,
                (double)nbatch * ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * sizeof(T));
+  ps.tag(d.M, d.N, d.K, (int64_t)nbatch * 1000 + (d.sAm == 1 ? 1 : 0) + (d.sBn != 1 ? 2 : 0) + (d.out_f32 ? 4 : 0) + (d.accumulate ? 8 : 0) + (ksplit > 1 ? 16 : 0));
   gemm_generic_kernel<T><<<(unsigned)blocks, 256, 0, c->stream>>>(g);
   SPA_LAUNCH_CHECK(c);
 }

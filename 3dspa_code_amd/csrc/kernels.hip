@@ -687,6 +687,100 @@ template <typename T> void k_bcast_grad(spa3d_ctx* c, const T* dsrc, int64_t per
 }
 
 // ---------------------------------------------------------------------------------------------
+// Dense layers with a tiny input width (K <= 4: the 1-channel depth feature, 3d:143-147).  As a GEMM this is a rank-K update of a
+// 3.4 M x 384 tensor: pure streaming.  out[crow(m)][:] += x[m][:K] . w[K][N] + bias, crow(m) = m + (m / G + 1) * S (token rows
+// 1..T of each sequence).  8 columns (16 B) per thread.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int K>
+__global__ void rank_fwd_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
+                                int64_t M, int N, int64_t ldo, int rgroup, int rskip) {
+  constexpr int NV = 8;
+  const int cpr = N / NV;
+  const int64_t total = M * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / cpr; const int c = (int)(i - m * cpr) * NV;
+    const int64_t crow = rgroup > 0 ? m + (m / rgroup + 1) * (int64_t)rskip : m;
+    float acc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float xv = ld(x + m * K + k);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) acc[j] = fmaf(xv, ld(w + (int64_t)k * N + c + j), acc[j]);
+    }
+    T* o = out + crow * ldo + c;
+    float cur[NV]; load_vec<T, NV>(o, cur);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) cur[j] += acc[j] + (bias ? bias[c + j] : 0.f);
+    store_vec<T, NV>(o, cur);
+  }
+}
+// gw[K][N] += x^T dY(rows remapped), gb[N] += colsum(dY): one pass over dY, per-block partials in registers, f32 atomics at the end
+template <typename T, int K>
+__global__ void rank_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t M, int N, int64_t ldy, int rgroup, int rskip,
+                                float* __restrict__ gw, float* __restrict__ gb, int64_t rows_per_block) {
+  constexpr int NV = 8;
+  const int cpr = N / NV;                       // column groups per row
+  const int slots = 256 / cpr;                  // rows processed per block iteration
+  const int slot = threadIdx.x / cpr, c = (threadIdx.x - slot * cpr) * NV;
+  if (slot >= slots) return;
+  const int64_t m0 = (int64_t)blockIdx.x * rows_per_block; int64_t m1 = m0 + rows_per_block; if (m1 > M) m1 = M;
+  float aw[K][NV], ab[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { ab[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) aw[k][j] = 0.f; }
+  for (int64_t m = m0 + slot; m < m1; m += slots) {
+    const int64_t row = rgroup > 0 ? m + (m / rgroup + 1) * (int64_t)rskip : m;
+    float d[NV]; load_vec<T, NV>(dy + row * ldy + c, d);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) ab[j] += d[j];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float xv = ld(x + m * K + k);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) aw[k][j] = fmaf(xv, d[j], aw[k][j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    if (gb) atomicAdd(gb + c + j, ab[j]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) atomicAdd(gw + (int64_t)k * N + c + j, aw[k][j]);
+  }
+}
+template <typename T>
+bool k_rank_fwd(spa3d_ctx* c, const T* x, const T* w, const float* bias, T* out, int64_t M, int N, int K, int64_t ldo, int rgroup, int rskip) {
+  if (K < 1 || K > 4 || N % 8 || ldo % 8 || (((uintptr_t)out) & 15) || (((uintptr_t)w) & 15)) return false;
+  if (c->dry || M == 0) return true;
+  const dim3 g = GRID1D(M * (N / 8), 256);
+  switch (K) {
+    case 1: rank_fwd_kernel<T, 1><<<g, 256, 0, c->stream>>>(x, w, bias, out, M, N, ldo, rgroup, rskip); break;
+    case 2: rank_fwd_kernel<T, 2><<<g, 256, 0, c->stream>>>(x, w, bias, out, M, N, ldo, rgroup, rskip); break;
+    case 3: rank_fwd_kernel<T, 3><<<g, 256, 0, c->stream>>>(x, w, bias, out, M, N, ldo, rgroup, rskip); break;
+    default: rank_fwd_kernel<T, 4><<<g, 256, 0, c->stream>>>(x, w, bias, out, M, N, ldo, rgroup, rskip); break;
+  }
+  SPA_LAUNCH_CHECK(c);
+  return true;
+}
+template <typename T>
+bool k_rank_bwd(spa3d_ctx* c, const T* x, const T* dy, int64_t M, int N, int K, int64_t ldy, int rgroup, int rskip, float* gw, float* gb) {
+  if (K < 1 || K > 4 || N % 8 || N / 8 > 256 || ldy % 8 || (((uintptr_t)dy) & 15)) return false;
+  if (c->dry || M == 0) return true;
+  const int64_t rpb = std::max<int64_t>(256, cdiv(M, 2048));
+  const unsigned g = (unsigned)cdiv(M, rpb);
+  switch (K) {
+    case 1: rank_bwd_kernel<T, 1><<<g, 256, 0, c->stream>>>(x, dy, M, N, ldy, rgroup, rskip, gw, gb, rpb); break;
+    case 2: rank_bwd_kernel<T, 2><<<g, 256, 0, c->stream>>>(x, dy, M, N, ldy, rgroup, rskip, gw, gb, rpb); break;
+    case 3: rank_bwd_kernel<T, 3><<<g, 256, 0, c->stream>>>(x, dy, M, N, ldy, rgroup, rskip, gw, gb, rpb); break;
+    default: rank_bwd_kernel<T, 4><<<g, 256, 0, c->stream>>>(x, dy, M, N, ldy, rgroup, rskip, gw, gb, rpb); break;
+  }
+  SPA_LAUNCH_CHECK(c);
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // D1: clip, discretise, fixed noise, straight-through (track_autoencoder_3d.py:251-260)
 // out = l - (l - q)  (same op order as the reference);  clipmask = 1[-1<=raw<=1] for the backward
 // ---------------------------------------------------------------------------------------------
@@ -1006,6 +1100,8 @@ void k_uniform_noise(spa3d_ctx* c, float* out, int64_t n, uint32_t k0, uint32_t 
   template void k_compact_tokens<T>(spa3d_ctx*, const T*, T*, int64_t, int, int);                                                      \
   template void k_broadcast_rows<T>(spa3d_ctx*, const float*, int, int, T*, int64_t);                                                  \
   template void k_bcast_grad<T>(spa3d_ctx*, const T*, int64_t, int64_t, int64_t, float*);                                              \
+  template bool k_rank_fwd<T>(spa3d_ctx*, const T*, const T*, const float*, T*, int64_t, int, int, int64_t, int, int);                \
+  template bool k_rank_bwd<T>(spa3d_ctx*, const T*, const T*, int64_t, int, int, int64_t, int, int, float*, float*);                                              \
   template void k_assemble_readout<T>(spa3d_ctx*, const T*, const T*, const int32_t*, int64_t, int, int, int, int, T*);                \
   template void k_assemble_readout_bwd<T>(spa3d_ctx*, const T*, const int32_t*, int64_t, int, int, int, int, T*, float*);              \
   template void k_loss_bwd<T>(spa3d_ctx*, const float*, int64_t, int, const float*, const float*, const float*, float, float, T*, int);

@@ -413,7 +413,9 @@ template <typename T> struct Net {
     }
     if (!twoD && g.depth_feature_dim > 0 && b->depth_features) {
       k.depthf = (const T*)b->depth_features + b0 * k.N * T_ * g.depth_feature_dim;
-      lin_fwd(depth, (const T*)k.depthf, k.tok0, nseq * T_, EPI_NONE, nullptr, 0, 1, 0, 0, T_, 1);
+      // 1-channel input: a rank-1 update of the token tensor, streamed (as a K=1 GEMM it ran at 1 TB/s); bf16 path only
+      if (!(sizeof(T) == 2 && depth.ldn == depth.N && k_rank_fwd<T>(c, (const T*)k.depthf, depth.wn, depth.bias, k.tok0, nseq * T_, depth.N, depth.K, d, T_, 1)))
+        lin_fwd(depth, (const T*)k.depthf, k.tok0, nseq * T_, EPI_NONE, nullptr, 0, 1, 0, 0, T_, 1);
     }
     k.km = alloc<float>(nseq * S);
     if (twoD) {
@@ -587,7 +589,8 @@ template <typename T> struct Net {
       // token rows 1..T of every sequence (row remap on the reduction index: no compaction copy)
       lin_bwd_w(tok, k.sinbuf, dtok, nseq * T_, 0, T_, 1);
       if (k.dino) lin_bwd_w(dino, (const T*)k.dino, dtok, nseq * T_, 0, T_, 1);
-      if (k.depthf) lin_bwd_w(depth, (const T*)k.depthf, dtok, nseq * T_, 0, T_, 1);
+      if (k.depthf && !(sizeof(T) == 2 && depth.nseg == 1 && k_rank_bwd<T>(c, (const T*)k.depthf, dtok, nseq * T_, depth.N, depth.K, d, T_, 1, depth.gw[0], depth.gb)))
+        lin_bwd_w(depth, (const T*)k.depthf, dtok, nseq * T_, 0, T_, 1);
     }
     c->ar.release(mk0);
   }
