@@ -1658,12 +1658,12 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   }
   // 8-phase kernels: 256x256 when 256 | N, 128x384 when 384 | N (see the kernel header for the measurements)
   if (c->nt_8p && (d.N % 256 == 0 || d.N % 384 == 0) && (d.M >= 256 * 64 || c->nt_8p == 2) && c->nt_8p != 3) {
-    if (d.N % 256 == 0 && c->nt_8pp && d.K >= 128 && !d.accumulate && d.crow_group == 0 && d.M % 8 == 0) {  // persistent form (accumulate would add loads to the counted wait)
+    if (d.N % 256 == 0 && c->nt_8pp && c->nt_8p != 44 && d.K >= 128 && !d.accumulate && d.crow_group == 0 && d.M % 8 == 0) {  // persistent form (accumulate would add loads to the counted wait)
       NtArgs g2 = g; g2.tiles_m = (int)((g.M + 255) / 256); g2.tiles_n = g.N / 256;
       static bool attrp = false;
       if (!attrp) { (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); attrp = true; }
       gemm_nt8pp_kernel<<<256, 512, 163840, c->stream>>>(g2);
-    } else if (d.N % 256 == 0) launch_nt8p<8, 4>(c, g); else launch_nt8p<4, 6>(c, g);
+    } else if (d.N % 256 == 0) { if (c->nt_8p == 44) launch_nt8p<4, 4>(c, g); else launch_nt8p<8, 4>(c, g); } else launch_nt8p<4, 6>(c, g);
     SPA_LAUNCH_CHECK(c);
     return true;
   }
