@@ -1556,18 +1556,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
     const int gn = cn0 + wc * 64 + c8 * 8;
     int rowl = wr * 128 + r8;
     asm volatile("" : "+v"(rowl));  // opaque per tile: otherwise sixteen 64-bit row addresses are hoisted out of the tile loop and spilled
-    uint4 auxv[4][2];  // four passes' worth at a time (all sixteen would spill)
-    auto load_aux = [&](int i0_) {
+    // The epilogue's only load (bias) is issued and consumed HERE, before the next tile's LDS-DMA: vmcnt retires in order and the
+    // compiler does not see the inline-asm LDS-DMA, so a load used after them would be waited for with a count that also covers the
+    // prologue's latency.  GEMMs with a residual / pre-activation operand take the non-persistent kernel (host).
+    float b8[8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 8; ++r) b8[r] = 0.f;
+    if (g.bias) { const float4 b0 = *(const float4*)(g.bias + gn), b1 = *(const float4*)(g.bias + gn + 4);
+      b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w; }
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int64_t gm = cm0 + (rowl + (i0_ + i) * 16 + it * 8);
-          auxv[i][it] = uint4{0, 0, 0, 0};
-          if (gm < g.M) auxv[i][it] = *(const uint4*)(g.aux + gm * g.ldc + gn);  // no output-row remap in this kernel (host)
-        }
-    };
-    if (g.aux) load_aux(0);
+    for (int r = 0; r < 8; ++r) asm volatile("" ::"v"(b8[r]));
     idx = next_valid(idx + nslot);
     const bool more = idx < per_xcd;
     if (more) {
@@ -1577,11 +1575,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
     }
     // ---- epilogue out of ring slot 2: wave-private [16 rows][16 chunks of 16 B] f32, chunk ^= row (conflict-free both ways)
     char* reg = smem + 2 * ASLOT + w * 4096;
-    float b8[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) b8[r] = 0.f;
-    if (g.bias) { const float4 b0 = *(const float4*)(g.bias + gn), b1 = *(const float4*)(g.bias + gn + 4);
-      b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w; }
 #pragma unroll
     for (int i = 0; i < WMT; ++i) {
 #pragma unroll
@@ -1594,17 +1587,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
         const f32x4 v1 = *(const f32x4*)(reg + row * 256 + (((2 * c8 + 1) ^ row) << 4));
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         const int64_t gm = cm0 + (rowl + i * 16 + it * 8);
-        if (gm < g.M) nt_store8<true, false>(g, gm, gn, v, b8, auxv[i & 3][it]);
+        if (gm < g.M) nt_store8<true, false>(g, gm, gn, v, b8);
       }
       __builtin_amdgcn_wave_barrier();
-      if (i == 3 && g.aux) load_aux(4);
     }
-    // every path consumes the aux registers here: otherwise the compiler's waitcnt pass carries "load possibly pending" to the
-    // K-loop header (it cannot correlate the load and use predicates) and drains vmcnt INSIDE the K-loop, LDS-DMA included
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int it = 0; it < 2; ++it) asm volatile("" ::"v"(auxv[i][it].x), "v"(auxv[i][it].y), "v"(auxv[i][it].z), "v"(auxv[i][it].w));
     if (!more) break;
     // the next tile's first K-tile has landed when only its second K-tile and this epilogue's stores can still be outstanding
     if (!interior) NT8P_WAIT_VM(0);
@@ -1658,7 +1644,7 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   }
   // 8-phase kernels: 256x256 when 256 | N, 128x384 when 384 | N (see the kernel header for the measurements)
   if (c->nt_8p && (d.N % 256 == 0 || d.N % 384 == 0) && (d.M >= 256 * 64 || c->nt_8p == 2) && c->nt_8p != 3) {
-    if (d.N % 256 == 0 && c->nt_8pp && c->nt_8p != 44 && d.K >= 128 && !d.accumulate && d.crow_group == 0 && d.M % 8 == 0) {  // persistent form (accumulate would add loads to the counted wait)
+    if (d.N % 256 == 0 && c->nt_8pp && c->nt_8p != 44 && d.K >= 128 && !d.accumulate && !d.aux && d.crow_group == 0 && d.M % 8 == 0) {  // persistent form (accumulate would add loads to the counted wait)
       NtArgs g2 = g; g2.tiles_m = (int)((g.M + 255) / 256); g2.tiles_n = g.N / 256;
       static bool attrp = false;
       if (!attrp) { (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); attrp = true; }
