@@ -1366,6 +1366,39 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(NtArgs g) {
   constexpr int CPR = WNT * 2;           // 8-column groups per row
   char* reg = smem + w * 16384;
   auto swz = [](int chunk, int row) { return WNT == 4 ? (chunk ^ (row & 15)) : ((chunk & ~7) | ((chunk & 7) ^ ((row >> 1) & 7))); };
+  constexpr int NIT = WMT * WNT / 4;
+  // residual / pre-activation operand: ALL of the tile's loads go out before the first store (vmcnt retires in order: a load issued
+  // after the first half's stores would be waited for together with their drain); 2 NIT x 4 VGPRs, the K-loop's fragments are dead
+  uint4 auxv[2][NIT];
+  if (g.aux) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int id = it * 64 + lane, row = id / CPR, c8 = id - row * CPR;
+        const int64_t gm = m0 + wr * (WMT * 16) + half * (WMT * 8) + row;
+        const int gn = n0 + wc * (WNT * 16) + c8 * 8;
+        auxv[half][it] = uint4{0, 0, 0, 0};
+        if (gm < g.M && gn < g.N) {
+          int64_t crow = gm;
+          if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
+          auxv[half][it] = *(const uint4*)(g.aux + crow * g.ldc + gn);
+        }
+      }
+  }
+  // bias likewise before the first store; a lane's column group is the same in every iteration when 64 % CPR == 0
+  constexpr bool CONSTC = (64 % CPR) == 0;
+  constexpr int NBV = CONSTC ? 1 : NIT;
+  float bv[NBV][8];
+#pragma unroll
+  for (int it = 0; it < NBV; ++it) {
+    const int id = it * 64 + lane, c8 = id % CPR;
+    const int gn = n0 + wc * (WNT * 16) + c8 * 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bv[it][r] = 0.f;
+    if (g.bias && gn < g.N) { const float4 b0 = *(const float4*)(g.bias + gn), b1 = *(const float4*)(g.bias + gn + 4);
+      bv[it][0] = b0.x; bv[it][1] = b0.y; bv[it][2] = b0.z; bv[it][3] = b0.w; bv[it][4] = b1.x; bv[it][5] = b1.y; bv[it][6] = b1.z; bv[it][7] = b1.w; }
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -1373,24 +1406,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(NtArgs g) {
 #pragma unroll
       for (int j = 0; j < WNT; ++j) *(f32x4*)(reg + (i * 16 + fr) * RB + (swz(j * 4 + fq, i * 16 + fr) << 4)) = acc[half * HM + i][j];
     __builtin_amdgcn_wave_barrier();  // same wave, LDS is in order: only the compiler must keep the order
-    constexpr int NIT = WMT * WNT / 4;
-    // residual / pre-activation operand: all of this pass's loads go out first (a load per iteration inside the loop keeps only
-    // two in flight per wave, and nothing else runs on the CU to hide them)
-    uint4 auxv[NIT];
-    if (g.aux) {
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int id = it * 64 + lane, row = id / CPR, c8 = id - row * CPR;
-        const int64_t gm = m0 + wr * (WMT * 16) + half * (WMT * 8) + row;
-        const int gn = n0 + wc * (WNT * 16) + c8 * 8;
-        auxv[it] = uint4{0, 0, 0, 0};
-        if (gm < g.M && gn < g.N) {
-          int64_t crow = gm;
-          if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
-          auxv[it] = *(const uint4*)(g.aux + crow * g.ldc + gn);
-        }
-      }
-    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int id = it * 64 + lane, row = id / CPR, c8 = id - row * CPR;
@@ -1399,16 +1414,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(NtArgs g) {
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       const int64_t gm = m0 + wr * (WMT * 16) + half * (WMT * 8) + row;
       const int gn = n0 + wc * (WNT * 16) + c8 * 8;
-      if (gm < g.M && gn < g.N) {
-        float b8[8];
-        if (g.bias) { const float4 b0 = *(const float4*)(g.bias + gn), b1 = *(const float4*)(g.bias + gn + 4);
-          b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w; }
-        else {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) b8[r] = 0.f;
-        }
-        nt_store8<true>(g, gm, gn, v, b8, auxv[it]);
-      }
+      if (gm < g.M && gn < g.N) nt_store8<true>(g, gm, gn, v, bv[CONSTC ? 0 : it], auxv[half][it]);
     }
     __builtin_amdgcn_wave_barrier();
   }
