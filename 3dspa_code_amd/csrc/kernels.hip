@@ -695,25 +695,41 @@ template <typename T, int K>
 __global__ void rank_fwd_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ out,
                                 int64_t M, int N, int64_t ldo, int rgroup, int rskip) {
   constexpr int NV = 8;
-  const int cpr = N / NV;
-  const int64_t total = M * cpr;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t m = i / cpr; const int c = (int)(i - m * cpr) * NV;
-    const int64_t crow = rgroup > 0 ? m + (m / rgroup + 1) * (int64_t)rskip : m;
-    float acc[NV];
+  const int cpr = N / NV;                   // column groups per row
+  const int slots = 256 / cpr;              // rows per block iteration (5 at N = 384)
+  const int slot = threadIdx.x / cpr, c = (threadIdx.x - slot * cpr) * NV;
+  if (slot >= slots) return;
+  float wv[K][NV], bvv[NV];                 // this thread's weight / bias columns: loaded once
 #pragma unroll
-    for (int j = 0; j < NV; ++j) acc[j] = 0.f;
+  for (int j = 0; j < NV; ++j) { bvv[j] = bias ? bias[c + j] : 0.f;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const float xv = ld(x + m * K + k);
+    for (int k = 0; k < K; ++k) wv[k][j] = ld(w + (int64_t)k * N + c + j); }
+  // four rows per iteration, all loads first: one 16-B load in flight per thread is latency-bound (1.5 TB/s)
+  constexpr int U = 4;
+  const int64_t stride = (int64_t)gridDim.x * slots;
+  for (int64_t m0 = (int64_t)blockIdx.x * slots + slot; m0 < M; m0 += stride * U) {
+    float cur[U][NV]; float xv[U][K]; T* o[U]; bool ok[U];
 #pragma unroll
-      for (int j = 0; j < NV; ++j) acc[j] = fmaf(xv, ld(w + (int64_t)k * N + c + j), acc[j]);
+    for (int u = 0; u < U; ++u) {
+      const int64_t m = m0 + u * stride; ok[u] = m < M;
+      const int64_t mm = ok[u] ? m : m0;
+      const int64_t crow = rgroup > 0 ? mm + ((unsigned)mm / (unsigned)rgroup + 1) * (int64_t)rskip : mm;  // M < 2^31 (host)
+      o[u] = out + crow * ldo + c;
+      load_vec<T, NV>(o[u], cur[u]);
+#pragma unroll
+      for (int k = 0; k < K; ++k) xv[u][k] = ld(x + mm * K + k);
     }
-    T* o = out + crow * ldo + c;
-    float cur[NV]; load_vec<T, NV>(o, cur);
 #pragma unroll
-    for (int j = 0; j < NV; ++j) cur[j] += acc[j] + (bias ? bias[c + j] : 0.f);
-    store_vec<T, NV>(o, cur);
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc = fmaf(xv[u][k], wv[k][j], acc);
+        cur[u][j] += acc + bvv[j];
+      }
+      if (ok[u]) store_vec<T, NV>(o[u], cur[u]);
+    }
   }
 }
 // gw[K][N] += x^T dY(rows remapped), gb[N] += colsum(dY): one pass over dY, per-block partials in registers, f32 atomics at the end
@@ -724,37 +740,67 @@ __global__ void rank_bwd_kernel(const T* __restrict__ x, const T* __restrict__ d
   const int cpr = N / NV;                       // column groups per row
   const int slots = 256 / cpr;                  // rows processed per block iteration
   const int slot = threadIdx.x / cpr, c = (threadIdx.x - slot * cpr) * NV;
-  if (slot >= slots) return;
   const int64_t m0 = (int64_t)blockIdx.x * rows_per_block; int64_t m1 = m0 + rows_per_block; if (m1 > M) m1 = M;
+  if (slot >= slots) m1 = m0;  // idle threads: no rows, but they take part in the barriers below
   float aw[K][NV], ab[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) { ab[j] = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) aw[k][j] = 0.f; }
-  for (int64_t m = m0 + slot; m < m1; m += slots) {
-    const int64_t row = rgroup > 0 ? m + (m / rgroup + 1) * (int64_t)rskip : m;
-    float d[NV]; load_vec<T, NV>(dy + row * ldy + c, d);
+  constexpr int U = 4;  // four rows per iteration, loads first
+  for (int64_t mb = m0 + slot; mb < m1; mb += (int64_t)slots * U) {
+    float d[U][NV]; float xv[U][K];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) ab[j] += d[j];
+    for (int u = 0; u < U; ++u) {
+      const int64_t m = mb + (int64_t)u * slots;
+      if (m < m1) {
+        const int64_t row = rgroup > 0 ? m + ((unsigned)m / (unsigned)rgroup + 1) * (int64_t)rskip : m;
+        load_vec<T, NV>(dy + row * ldy + c, d[u]);
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const float xv = ld(x + m * K + k);
+        for (int k = 0; k < K; ++k) xv[u][k] = ld(x + m * K + k);
+      } else {
 #pragma unroll
-      for (int j = 0; j < NV; ++j) aw[k][j] = fmaf(xv, d[j], aw[k][j]);
+        for (int j = 0; j < NV; ++j) d[u][j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) xv[u][k] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) ab[j] += d[u][j];
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) aw[k][j] = fmaf(xv[u][k], d[u][j], aw[k][j]);
     }
   }
+  // block-level reduction over the row slots in LDS, then ONE global atomic per column per block (all blocks hit the same 2 N addresses)
+  __shared__ float red[(K + 1) * 2048];  // (K + 1) x N floats, N <= 2048 (N / 8 <= 256 column groups)
+  float* rw = red; float* rb = red + (int64_t)K * N;
+  __syncthreads();
+  for (int t = threadIdx.x; t < (K + 1) * N; t += 256) red[t] = 0.f;
+  __syncthreads();
+  if (slot < slots) {
 #pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    if (gb) atomicAdd(gb + c + j, ab[j]);
+    for (int j = 0; j < NV; ++j) {
+      atomicAdd(rb + c + j, ab[j]);
 #pragma unroll
-    for (int k = 0; k < K; ++k) atomicAdd(gw + (int64_t)k * N + c + j, aw[k][j]);
+      for (int k = 0; k < K; ++k) atomicAdd(rw + k * N + c + j, aw[k][j]);
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < N; t += 256) {
+    if (gb) atomicAdd(gb + t, rb[t]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) atomicAdd(gw + (int64_t)k * N + t, rw[k * N + t]);
   }
 }
 template <typename T>
 bool k_rank_fwd(spa3d_ctx* c, const T* x, const T* w, const float* bias, T* out, int64_t M, int N, int K, int64_t ldo, int rgroup, int rskip) {
-  if (K < 1 || K > 4 || N % 8 || ldo % 8 || (((uintptr_t)out) & 15) || (((uintptr_t)w) & 15)) return false;
+  if (K < 1 || K > 4 || N % 8 || N / 8 > 256 || ldo % 8 || (((uintptr_t)out) & 15) || M >= 0x7fffffffLL) return false;
   if (c->dry || M == 0) return true;
-  const dim3 g = GRID1D(M * (N / 8), 256);
+  const dim3 g = GRID1D(cdiv(M, 4 * (256 / (N / 8))) * 256, 256);
   switch (K) {
     case 1: rank_fwd_kernel<T, 1><<<g, 256, 0, c->stream>>>(x, w, bias, out, M, N, ldo, rgroup, rskip); break;
     case 2: rank_fwd_kernel<T, 2><<<g, 256, 0, c->stream>>>(x, w, bias, out, M, N, ldo, rgroup, rskip); break;
@@ -766,9 +812,9 @@ bool k_rank_fwd(spa3d_ctx* c, const T* x, const T* w, const float* bias, T* out,
 }
 template <typename T>
 bool k_rank_bwd(spa3d_ctx* c, const T* x, const T* dy, int64_t M, int N, int K, int64_t ldy, int rgroup, int rskip, float* gw, float* gb) {
-  if (K < 1 || K > 4 || N % 8 || N / 8 > 256 || ldy % 8 || (((uintptr_t)dy) & 15)) return false;
+  if (K < 1 || K > 4 || N % 8 || N / 8 > 256 || ldy % 8 || (((uintptr_t)dy) & 15) || M >= 0x7fffffffLL) return false;
   if (c->dry || M == 0) return true;
-  const int64_t rpb = std::max<int64_t>(256, cdiv(M, 2048));
+  const int64_t rpb = std::max<int64_t>(256, cdiv(M, 1024));
   const unsigned g = (unsigned)cdiv(M, rpb);
   switch (K) {
     case 1: rank_bwd_kernel<T, 1><<<g, 256, 0, c->stream>>>(x, dy, M, N, ldy, rgroup, rskip, gw, gb, rpb); break;
@@ -835,10 +881,41 @@ __global__ void assemble_kernel(const T* __restrict__ qtok, const T* __restrict_
     seq[i] = v;
   }
 }
+// 8 elements per thread (one 16-B store), 32-bit index math; only the window part (Cl <= j, source shifted by 5 t_q elements, hence
+// unaligned) gathers element-wise.  Needs D % 8 == 0, Cl % 8 == 0 and < 2^31 chunks (else the scalar kernel above).
+template <typename T>
+__global__ void assemble_vec_kernel(const T* __restrict__ qtok, const T* __restrict__ lat, const int32_t* __restrict__ qframe, unsigned nchunk,
+                                    int Q, int L, int Cl, int D, T* __restrict__ seq) {
+  constexpr int NV = VecOf<T>::N;
+  const unsigned cpr = (unsigned)D / NV;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < nchunk; i += gridDim.x * 256u) {
+    const unsigned row = i / cpr; const int j = (int)(i - row * cpr) * NV;
+    const unsigned bq = row / (unsigned)(L + 1); const int tkn = (int)(row - bq * (unsigned)(L + 1));
+    float v[NV];
+    if (tkn == 0) load_vec<T, NV>(qtok + (int64_t)bq * D + j, v);
+    else {
+      const unsigned b = bq / (unsigned)Q;
+      const T* lr = lat + ((int64_t)b * L + (tkn - 1)) * Cl;
+      if (j < Cl) load_vec<T, NV>(lr + j, v);
+      else {
+        const int base = j - Cl + 5 * qframe[bq];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) { const int cc = base + e; v[e] = (cc >= 0 && cc < Cl) ? ld(lr + cc) : 0.f; }
+      }
+    }
+    store_vec<T, NV>(seq + (int64_t)row * D + j, v);
+  }
+}
 template <typename T>
 void k_assemble_readout(spa3d_ctx* c, const T* qtok, const T* lat, const int32_t* qframe, int64_t B, int Q, int L, int Cl, int D, T* seq) {
   if (c->dry || B == 0) return;
-  assemble_kernel<T><<<GRID1D(B * Q * (L + 1) * D, 256), 256, 0, c->stream>>>(qtok, lat, qframe, B * Q, Q, L, Cl, D, seq);
+  constexpr int NV = VecOf<T>::N;
+  const int64_t nchunk = B * Q * (L + 1) * (D / NV);
+  if (D % NV == 0 && Cl % NV == 0 && nchunk < 0x7fffffffLL && ((((uintptr_t)qtok) | ((uintptr_t)lat) | ((uintptr_t)seq)) & 15) == 0) {
+    assemble_vec_kernel<T><<<GRID1D(nchunk, 256), 256, 0, c->stream>>>(qtok, lat, qframe, (unsigned)nchunk, Q, L, Cl, D, seq);
+  } else {
+    assemble_kernel<T><<<GRID1D(B * Q * (L + 1) * D, 256), 256, 0, c->stream>>>(qtok, lat, qframe, B * Q, Q, L, Cl, D, seq);
+  }
   SPA_LAUNCH_CHECK(c);
 }
 // backward: dqtok = dseq[:, :, 0, :] ; dlat[b][n][c] = sum_q dseq[b][q][1+n][c] + sum_q dseq[b][q][1+n][Cl + c-5t_q] 1[0<=c-5t_q<D-Cl]
@@ -850,14 +927,18 @@ __global__ void assemble_bwd_lat_kernel(const T* __restrict__ dseq, const int32_
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
     int64_t bn = i / Cl; int cc = (int)(i - bn * Cl);
     int64_t b = bn / L; int n = (int)(bn - b * L);
-    float s = 0.f;
-    for (int q = 0; q < Q; ++q) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // independent chains: 512 dependent strided loads were pure latency
+    auto term = [&](int q) {
       const T* r = dseq + (((b * Q + q) * (L + 1)) + 1 + n) * D;
-      s += ld(r + cc);
-      int64_t dd = (int64_t)cc - 5 * (int64_t)qframe[b * Q + q];
-      if (dd >= 0 && dd < Wd) s += ld(r + Cl + dd);
-    }
-    dlat[i] = s;
+      float t = ld(r + cc);
+      const int dd = cc - 5 * qframe[b * Q + q];
+      if (dd >= 0 && dd < Wd) t += ld(r + Cl + dd);
+      return t;
+    };
+    int q = 0;
+    for (; q + 3 < Q; q += 4) { s0 += term(q); s1 += term(q + 1); s2 += term(q + 2); s3 += term(q + 3); }
+    for (; q < Q; ++q) s0 += term(q);
+    dlat[i] = (s0 + s1) + (s2 + s3);
   }
 }
 template <typename T>
