@@ -177,7 +177,8 @@ void k_layernorm(spa3d_ctx* c, const T* x, const float* scale, T* y, float* stat
   constexpr int NV = VecOf<T>::N;
   const bool al = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
   if (d % NV == 0 && al && d <= 64 * NV * 4) {
-    const unsigned g = (unsigned)std::min<int64_t>(cdiv(rows, 8), 16384);
+    static int gcap = -1; if (gcap < 0) { const char* e = getenv("SPA3D_LN_GRID"); gcap = e ? atoi(e) : 4096; }
+    const unsigned g = (unsigned)std::min<int64_t>(cdiv(rows, 8), gcap);
     const int steps = (d / NV + 63) / 64;
     if (steps == 1) ln_fwd_vec_kernel<T, 1><<<g, 256, 0, c->stream>>>(x, scale, y, stats, rows, d);
     else if (steps == 2) ln_fwd_vec_kernel<T, 2><<<g, 256, 0, c->stream>>>(x, scale, y, stats, rows, d);
@@ -259,7 +260,8 @@ template <typename T>
 void k_layernorm_bwd(spa3d_ctx* c, const T* x, const float* scale, const float* stats, const T* dy, T* dx, float* dscale,
                      int64_t rows, int d, const T* add) {
   if (c->dry || rows == 0) return;
-  unsigned g = (unsigned)std::min<int64_t>(cdiv(rows, 4), 2048);
+  static int gcapb = -1; if (gcapb < 0) { const char* e = getenv("SPA3D_LNB_GRID"); gcapb = e ? atoi(e) : 1024; }
+  unsigned g = (unsigned)std::min<int64_t>(cdiv(rows, 4), gcapb);
   constexpr int NV = VecOf<T>::N;
   const bool al = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)add)) & 15) == 0;
   if (d % NV == 0 && al && d <= 64 * NV * 4) {
