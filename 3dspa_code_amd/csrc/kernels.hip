@@ -261,7 +261,7 @@ void k_layernorm_bwd(spa3d_ctx* c, const T* x, const float* scale, const float* 
                      int64_t rows, int d, const T* add) {
   if (c->dry || rows == 0) return;
   static int gcapb = -1; if (gcapb < 0) { const char* e = getenv("SPA3D_LNB_GRID"); gcapb = e ? atoi(e) : 1024; }
-  unsigned g = (unsigned)std::min<int64_t>(cdiv(rows, 4), gcapb);
+  unsigned g = (unsigned)std::min<int64_t>(cdiv(rows, 4), d <= 512 ? gcapb : 2 * gcapb);  // measured: 1024 blocks at d = 384, 2048 at d = 1280
   constexpr int NV = VecOf<T>::N;
   const bool al = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)add)) & 15) == 0;
   if (d % NV == 0 && al && d <= 64 * NV * 4) {
