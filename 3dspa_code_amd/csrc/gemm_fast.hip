@@ -24,6 +24,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
 
 #define GLDS16(gptr, lptr) \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+// same with the non-temporal cache policy (aux bit 1): an operand that is read exactly once
+#define GLDS16_NT(gptr, lptr) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 2)
 
 // LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit lane offset: keeps per-lane addressing at one VGPR per load
 // (the builtin form is free to widen the offsets to 64 bits, which in the persistent kernel spilled them into the K-loop)
@@ -1284,12 +1287,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(NtArgs g) {
       pb[h][i] = g.Bt + (int64_t)bn * g.ldb + sc; lb[h][i] = BOFF + rb * 128;
     }
   }
+  const bool a_once = g.tiles_n == 1 && g.dbg != 8;  // the A panel is read by this workgroup only: stream it past L2 (dbg 8: off, for A/B)
   auto stageA = [&](int kt, int slot) {  // both halves of K-tile kt
     char* base = smem + slot * ASLOT;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int i = 0; i < NA; ++i) GLDS16(pa[h][i] + kt * 64, base + la[h][i]);
+      for (int i = 0; i < NA; ++i) { if (a_once) GLDS16_NT(pa[h][i] + kt * 64, base + la[h][i]); else GLDS16(pa[h][i] + kt * 64, base + la[h][i]); }
   };
   auto stageB = [&](int h, int kt) {
     char* base = smem + (kt & 1) * BBUF;
