@@ -116,6 +116,7 @@ struct spa3d_ctx {
                       // SPA3D_NT_ASTAT2=1 enables, =2 forces small M (tests)
   int nt_8p = 1;      // 8-phase kernels (256x256 / 128x384, counted vmcnt, staggered wave rows); 2 = also for small M, 0/3 = off
   int tn_8p = 1;      // 8-phase TN (dW) kernels; SPA3D_TN_8P=0 disables, =2 forces (tests)
+  int tn_qp = 2;      // quarters (16 reduction rows) per phase of the 8-phase TN kernels: 2 = 16 MFMAs per barrier pair (+7-10 %), 1 = 8
   int tn_rounds = 0;  // 0: M-split count of the 8-phase TN kernels from the makespan model; > 0: 256 * rounds / tiles (experiments)
   int nt_8pp = 1;     // persistent form of the 256x256 8-phase NT kernel (SPA3D_NT_8PP=0 disables): +3-6 %
   int nt_stream = 1;  // non-temporal stores for bf16 GEMM outputs >= 512 MB (SPA3D_NT_STREAM=0 disables)

@@ -1865,11 +1865,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
 //   streamed from HBM and get an 8-phase lead.  Wave-row 1 runs one barrier behind wave-row 0 (one wave of each per SIMD), so
 //   one reads/stages while the other issues MFMAs.  Hazard rules as in the NT kernel (cdna_hip_programming.md, 8-phase template).
 // =================================================================================================================
-template <int WIT, int WNT>
+// QP = quarters per phase.  QP = 2: 16 MFMAs (512 cycles) between barrier pairs instead of 8, so one wave-row's MFMA section covers
+// the other's 24 transposed reads and their LDS latency (with QP = 1 the read/stage section is the longer one: ~46 % MFMA-busy);
+// the lead shrinks to 6 quarters (the slot of quarter q+6 was last read two phases ago).
+template <int WIT, int WNT, int QP>
 __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs g) {
   constexpr int TI = 64 * WIT, TNN = 128 * WNT, NSA = TI / 128;
   static_assert(TI / 128 + TNN / 128 == 4, "four sub-images per quarter");
-  constexpr int R = 10, D = 8, QB = 16384;
+  constexpr int R = 10, D = QP == 1 ? 8 : 6, QB = 16384;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int xcd = blockIdx.x & 7; int jb = blockIdx.x >> 3;
   const int ntile = g.tiles_i * g.tiles_n;
@@ -1965,43 +1968,54 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs g) {
 #pragma unroll
   for (int j = 0; j < WNT; ++j) cs[j] = 0.f;
   const unsigned ones2 = 0x3F803F80u;
-  const int npro = nq < D ? nq : D;
+  const int nqp = (nq + QP - 1) / QP * QP;  // padded to whole phases: the extra quarter lies past mend and stages the zero page
+  const int npro = nqp < D ? nqp : D;
   for (int q = 0; q < npro; ++q) stage();
-  if (nq >= D) NT8P_WAIT_VM(2 * (D - 1)); else NT8P_WAIT_VM(0);
-  NT8P_BAR();                 // quarter 0 is visible to every wave
+  if (nqp >= D) NT8P_WAIT_VM(2 * (D - QP)); else NT8P_WAIT_VM(0);
+  NT8P_BAR();                 // the first phase's quarters are visible to every wave
   if (wr == 1) NT8P_BAR();    // the stagger
   int slot = 0;
-  for (int q = 0; q < nq; ++q) {
+  for (int q = 0; q < nqp; q += QP) {
     const char* sq = smem + slot * QB;
-    uint2 fb[WNT][2], fa[WIT][2];
+    uint2 fb[QP][WNT][2], fa[QP][WIT][2];
 #pragma unroll
-    for (int j = 0; j < WNT; ++j) { fb[j][0] = ds_read_tr16_b64(sq + offb[j][0]); fb[j][1] = ds_read_tr16_b64(sq + offb[j][1]); }
+    for (int u = 0; u < QP; ++u) {
 #pragma unroll
-    for (int i = 0; i < WIT; ++i) { fa[i][0] = ds_read_tr16_b64(sq + offa[i][0]); fa[i][1] = ds_read_tr16_b64(sq + offa[i][1]); }
-    if (q + D < nq) { stage(); NT8P_WAIT_VM(2 * (D - 1)); }   // quarters q+2 .. q+D stay in flight, q+1 has landed (this wave's part)
-    else NT8P_WAIT_VM(0);
+      for (int j = 0; j < WNT; ++j) { fb[u][j][0] = ds_read_tr16_b64(sq + u * QB + offb[j][0]); fb[u][j][1] = ds_read_tr16_b64(sq + u * QB + offb[j][1]); }
+#pragma unroll
+      for (int i = 0; i < WIT; ++i) { fa[u][i][0] = ds_read_tr16_b64(sq + u * QB + offa[i][0]); fa[u][i][1] = ds_read_tr16_b64(sq + u * QB + offa[i][1]); }
+    }
+    if (q + D < nqp) {   // the next phase's quarters have landed (this wave's part); D - QP quarters stay in flight
+#pragma unroll
+      for (int u = 0; u < QP; ++u) stage();
+      NT8P_WAIT_VM(2 * (D - QP));
+    } else NT8P_WAIT_VM(0);
     NT8P_BAR();
     NT8P_WAIT_LGKM(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < WIT; ++i) {
-      const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(fa[i][0].x, fa[i][0].y, fa[i][1].x, fa[i][1].y));
+    for (int u = 0; u < QP; ++u)
 #pragma unroll
-      for (int j = 0; j < WNT; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, make_uint4(fb[j][0].x, fb[j][0].y, fb[j][1].x, fb[j][1].y)), acc[i][j], 0, 0, 0);
-    }
+      for (int i = 0; i < WIT; ++i) {
+        const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(fa[u][i][0].x, fa[u][i][0].y, fa[u][i][1].x, fa[u][i][1].y));
+#pragma unroll
+        for (int j = 0; j < WNT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, make_uint4(fb[u][j][0].x, fb[u][j][0].y, fb[u][j][1].x, fb[u][j][1].y)), acc[i][j], 0, 0, 0);
+      }
     if (do_cs) {
 #pragma unroll
-      for (int j = 0; j < WNT; ++j) {
-        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[j]) : "v"(fb[j][0].x), "v"(ones2));
-        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[j]) : "v"(fb[j][0].y), "v"(ones2));
-        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[j]) : "v"(fb[j][1].x), "v"(ones2));
-        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[j]) : "v"(fb[j][1].y), "v"(ones2));
-      }
+      for (int u = 0; u < QP; ++u)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+          asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[j]) : "v"(fb[u][j][0].x), "v"(ones2));
+          asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[j]) : "v"(fb[u][j][0].y), "v"(ones2));
+          asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[j]) : "v"(fb[u][j][1].x), "v"(ones2));
+          asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[j]) : "v"(fb[u][j][1].y), "v"(ones2));
+        }
     }
     __builtin_amdgcn_s_setprio(0);
     NT8P_BAR();
-    slot = slot == R - 1 ? 0 : slot + 1;
+    slot += QP; if (slot >= R) slot -= R;
   }
   if (wr == 0) NT8P_BAR();
   if (do_cs) {
@@ -2027,8 +2041,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs g) {
     }
 }
 
-template <int WIT, int WNT>
-static void launch_tn8p(spa3d_ctx* c, TnArgs g, int rounds) {
+template <int WIT, int WNT, int QP>
+static void launch_tn8p_q(spa3d_ctx* c, TnArgs g, int rounds) {
   constexpr int TI = 64 * WIT, TNN = 128 * WNT;
   g.tiles_i = (g.Ki + TI - 1) / TI; g.tiles_n = (g.N + TNN - 1) / TNN;
   const int64_t tiles = (int64_t)g.tiles_i * g.tiles_n;
@@ -2052,8 +2066,13 @@ static void launch_tn8p(spa3d_ctx* c, TnArgs g, int rounds) {
   splits = (g.M + rps - 1) / rps;
   g.splits = (int)splits; g.rows_per_split = rps;
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn8p_kernel<WIT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); attr = true; }
-  gemm_tn8p_kernel<WIT, WNT><<<(unsigned)(tiles * ((splits + 7) / 8 * 8)), 512, 163840, c->stream>>>(g);
+  if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn8p_kernel<WIT, WNT, QP>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); attr = true; }
+  gemm_tn8p_kernel<WIT, WNT, QP><<<(unsigned)(tiles * ((splits + 7) / 8 * 8)), 512, 163840, c->stream>>>(g);
+}
+
+template <int WIT, int WNT>
+static void launch_tn8p(spa3d_ctx* c, const TnArgs& g, int rounds) {
+  if (c->tn_qp == 2) launch_tn8p_q<WIT, WNT, 2>(c, g, rounds); else launch_tn8p_q<WIT, WNT, 1>(c, g, rounds);
 }
 
 bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d) {

@@ -18,6 +18,7 @@ struct OpCtx : spa3d_ctx {
     e = getenv("SPA3D_NT_8PP"); if (e) nt_8pp = atoi(e);
     e = getenv("SPA3D_NT_STREAM"); if (e) nt_stream = atoi(e);
     e = getenv("SPA3D_TN_8P"); if (e) tn_8p = atoi(e);
+    e = getenv("SPA3D_TN_QP"); if (e) tn_qp = atoi(e);
     e = getenv("SPA3D_TN_ROUNDS"); if (e) tn_rounds = atoi(e);
     e = getenv("SPA3D_NT_ASTAT2"); if (e) nt_astat2 = atoi(e);
   }
