@@ -119,6 +119,7 @@ struct spa3d_ctx {
   int tn_qp = 2;      // quarters (16 reduction rows) per phase of the 8-phase TN kernels: 2 = 16 MFMAs per barrier pair (+7-10 %), 1 = 8
   int tn_rounds = 0;  // 0: M-split count of the 8-phase TN kernels from the makespan model; > 0: 256 * rounds / tiles (experiments)
   int nt_8pp = 1;     // persistent form of the 256x256 8-phase NT kernel (SPA3D_NT_8PP=0 disables): +3-6 %
+  int nt_coarse = 1;  // persistent NT kernel with two phases per K-tile (32 MFMAs per barrier pair) instead of four (SPA3D_NT_COARSE)
   int nt_stream = 1;  // non-temporal stores for bf16 GEMM outputs >= 512 MB (SPA3D_NT_STREAM=0 disables)
   int nt_ring = 0;    // persistent 256x128 kernels, measured SLOWER than the 128x128 ones (500-740 vs 660-885 TF/s), off:
                       // SPA3D_NT_RING=1 ping-pong teams (staggered by one barrier), =3 plain ring; =2 ping-pong forced for small M (tests)

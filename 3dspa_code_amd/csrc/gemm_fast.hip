@@ -1442,6 +1442,7 @@ static void launch_nt8p(spa3d_ctx* c, const NtArgs& g) {
 // stores too (MI355X_MICROARCH.md "s_waitcnt vmcnt(N)"), so "all but the second K-tile's loads and this epilogue's stores" means
 // the first K-tile has landed while the stores are still draining.  Edge tiles (rows past M) skip stores, so they drain to 0.
 // =================================================================================================================
+template <bool COARSE>
 __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
   constexpr int WMT = 8, WNT = 4, BM = 256, BN = 256, NA = 2, NB = 2, HM = 4, HN = 2;
   constexpr int ASLOT = BM * 128, BBUF = BN * 128, BOFF = 3 * ASLOT, NKT = 2 * NA + 2 * NB;
@@ -1525,6 +1526,35 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
     for (int t = 0; t < nt; ++t) {
       const char* sa = smem + aslot * ASLOT;
       const char* sb = smem + (t & 1) * BBUF;
+      if constexpr (COARSE) {
+        // two phases per K-tile, 32 MFMAs (512 cycles) per barrier pair: one wave-row's MFMA section covers the other's 16 reads and
+        // their LDS latency.  Every read is retired BEFORE its phase's first barrier, so a slot may be restaged one phase later.
+        // ---------------- PA: B-q0, B-q1 (retired first), A-q0 | stage A(t+2) | quadrants (0,0) (0,1)
+#pragma unroll
+        for (int j = 0; j < HN; ++j) { bq0[j][0] = *(const bf16x8*)(sb + b_off + j * 2048 + x0); bq0[j][1] = *(const bf16x8*)(sb + b_off + j * 2048 + x1); }
+#pragma unroll
+        for (int j = 0; j < HN; ++j) { bq1[j][0] = *(const bf16x8*)(sb + b_off + (HN + j) * 2048 + x0); bq1[j][1] = *(const bf16x8*)(sb + b_off + (HN + j) * 2048 + x1); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < HM; ++i) { aq[i][0] = *(const bf16x8*)(sa + a_off + i * 2048 + x0); aq[i][1] = *(const bf16x8*)(sa + a_off + i * 2048 + x1); }
+        if (t + 2 < nt) stageA(t + 2, aslot2);   // slot of K-tile t-1: its A-q1 reads were retired before the previous phase's barrier
+        NT8P_WAIT_LGKM(2 * HM);                  // the B reads have returned: both B halves may be restaged next phase
+        NT8P_BAR();
+        NT8P_WAIT_LGKM(0);
+        NT8P_MFMA(0, 0, bq0)
+        NT8P_MFMA(0, HN, bq1)
+        NT8P_BAR();
+        // ---------------- PB: A-q1 (retired before the barrier) | stage B-h0(t+2), B-h1(t+2) | wait K-tile t+1 | quadrants (1,1) (1,0)
+#pragma unroll
+        for (int i = 0; i < HM; ++i) { aq[i][0] = *(const bf16x8*)(sa + a_off + (HM + i) * 2048 + x0); aq[i][1] = *(const bf16x8*)(sa + a_off + (HM + i) * 2048 + x1); }
+        if (t + 2 < nt) { stageB(0, t + 2); stageB(1, t + 2); NT8P_WAIT_VM(NKT); }
+        else NT8P_WAIT_VM(0);
+        NT8P_WAIT_LGKM(0);
+        NT8P_BAR();
+        NT8P_MFMA(HM, HN, bq1)
+        NT8P_MFMA(HM, 0, bq0)
+        NT8P_BAR();
+      } else {
 #pragma unroll
       for (int j = 0; j < HN; ++j) { bq0[j][0] = *(const bf16x8*)(sb + b_off + j * 2048 + x0); bq0[j][1] = *(const bf16x8*)(sb + b_off + j * 2048 + x1); }
       __builtin_amdgcn_sched_barrier(0);
@@ -1554,6 +1584,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
       NT8P_BAR();
       NT8P_MFMA(HM, 0, bq0)
       NT8P_BAR();
+      }
       aslot = aslot == 2 ? 0 : aslot + 1; aslot2 = aslot2 == 2 ? 0 : aslot2 + 1;
     }
 #undef NT8P_MFMA
@@ -1657,8 +1688,10 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
     if (d.N % 256 == 0 && c->nt_8pp && c->nt_8p != 44 && d.K >= 128 && !d.accumulate && !d.aux && d.crow_group == 0 && d.M % 8 == 0) {  // persistent form (accumulate would add loads to the counted wait)
       NtArgs g2 = g; g2.tiles_m = (int)((g.M + 255) / 256); g2.tiles_n = g.N / 256;
       static bool attrp = false;
-      if (!attrp) { (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); attrp = true; }
-      gemm_nt8pp_kernel<<<256, 512, 163840, c->stream>>>(g2);
+      if (!attrp) { (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); attrp = true; }
+      if (c->nt_coarse) gemm_nt8pp_kernel<true><<<256, 512, 163840, c->stream>>>(g2);
+      else gemm_nt8pp_kernel<false><<<256, 512, 163840, c->stream>>>(g2);
     } else if (d.N % 256 == 0) { if (c->nt_8p == 44) launch_nt8p<4, 4>(c, g); else launch_nt8p<8, 4>(c, g); } else launch_nt8p<4, 6>(c, g);
     SPA_LAUNCH_CHECK(c);
     return true;

@@ -731,6 +731,7 @@ int spa3d_create(const spa3d_config* cfg, spa3d_handle* out) {
   e = getenv("SPA3D_NT_RING"); if (e) c->nt_ring = atoi(e);
   e = getenv("SPA3D_NT_8P"); if (e) c->nt_8p = atoi(e);
   e = getenv("SPA3D_NT_8PP"); if (e) c->nt_8pp = atoi(e);
+  e = getenv("SPA3D_NT_COARSE"); if (e) c->nt_coarse = atoi(e);
   e = getenv("SPA3D_NT_STREAM"); if (e) c->nt_stream = atoi(e);
   e = getenv("SPA3D_TN_8P"); if (e) c->tn_8p = atoi(e);
   e = getenv("SPA3D_TN_QP"); if (e) c->tn_qp = atoi(e);

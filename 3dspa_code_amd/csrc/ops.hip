@@ -16,6 +16,7 @@ struct OpCtx : spa3d_ctx {
     e = getenv("SPA3D_NT_RING"); if (e) nt_ring = atoi(e);
     e = getenv("SPA3D_NT_8P"); if (e) nt_8p = atoi(e);
     e = getenv("SPA3D_NT_8PP"); if (e) nt_8pp = atoi(e);
+    e = getenv("SPA3D_NT_COARSE"); if (e) nt_coarse = atoi(e);
     e = getenv("SPA3D_NT_STREAM"); if (e) nt_stream = atoi(e);
     e = getenv("SPA3D_TN_8P"); if (e) tn_8p = atoi(e);
     e = getenv("SPA3D_TN_QP"); if (e) tn_qp = atoi(e);
