@@ -1250,7 +1250,7 @@ __device__ __forceinline__ void nt_store4(const NtArgs& g, int64_t gm, int gn, c
 
 // WMT x WNT = 16x16 output tiles per wave; waves 2(M) x 4(N); tile = (32 WMT) x (64 WNT): <8,4> = 256x256, <4,6> = 128x384
 // (N = 384 in ONE tile: the A panel is read from HBM exactly once).  64 KiB per LDS buffer in both.
-template <int WMT, int WNT>
+template <int WMT, int WNT, bool COARSE = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(NtArgs g) {
   constexpr int BM = 32 * WMT, BN = 64 * WNT;
   constexpr int NA = WMT / 4, NB = WNT / 2;   // LDS-DMA per thread per A / B half-tile
@@ -1324,6 +1324,35 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(NtArgs g) {
   for (int t = 0; t < nt; ++t) {
     const char* sa = smem + aslot * ASLOT;
     const char* sb = smem + (t & 1) * BBUF;
+    if constexpr (COARSE) {
+      // two phases per K-tile (2 HM HN x 2 MFMAs per barrier pair): one wave-row's MFMA section covers the other's reads and their
+      // LDS latency.  Every read is retired BEFORE its phase's first barrier, so a slot may be restaged one phase later.
+      // ---------------- PA: B-q0, B-q1 (retired first), A-q0 | stage A(t+2) | quadrants (0,0) (0,1)
+#pragma unroll
+      for (int j = 0; j < HN; ++j) { bq0[j][0] = *(const bf16x8*)(sb + b_off + j * 2048 + x0); bq0[j][1] = *(const bf16x8*)(sb + b_off + j * 2048 + x1); }
+#pragma unroll
+      for (int j = 0; j < HN; ++j) { bq1[j][0] = *(const bf16x8*)(sb + b_off + (HN + j) * 2048 + x0); bq1[j][1] = *(const bf16x8*)(sb + b_off + (HN + j) * 2048 + x1); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < HM; ++i) { aq[i][0] = *(const bf16x8*)(sa + a_off + i * 2048 + x0); aq[i][1] = *(const bf16x8*)(sa + a_off + i * 2048 + x1); }
+      if (t + 2 < nt) stageA(t + 2, aslot2);
+      NT8P_WAIT_LGKM(2 * HM);
+      NT8P_BAR();
+      NT8P_WAIT_LGKM(0);
+      NT8P_MFMA(0, 0, bq0)
+      NT8P_MFMA(0, HN, bq1)
+      NT8P_BAR();
+      // ---------------- PB: A-q1 (retired before the barrier) | stage B-h0(t+2), B-h1(t+2) | wait K-tile t+1 | quadrants (1,1) (1,0)
+#pragma unroll
+      for (int i = 0; i < HM; ++i) { aq[i][0] = *(const bf16x8*)(sa + a_off + (HM + i) * 2048 + x0); aq[i][1] = *(const bf16x8*)(sa + a_off + (HM + i) * 2048 + x1); }
+      if (t + 2 < nt) { stageB(0, t + 2); stageB(1, t + 2); NT8P_WAIT_VM(NKT); }
+      else NT8P_WAIT_VM(0);
+      NT8P_WAIT_LGKM(0);
+      NT8P_BAR();
+      NT8P_MFMA(HM, HN, bq1)
+      NT8P_MFMA(HM, 0, bq0)
+      NT8P_BAR();
+    } else {
     // ---------------- P0
 #pragma unroll
     for (int j = 0; j < HN; ++j) { bq0[j][0] = *(const bf16x8*)(sb + b_off + j * 2048 + x0); bq0[j][1] = *(const bf16x8*)(sb + b_off + j * 2048 + x1); }
@@ -1357,6 +1386,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(NtArgs g) {
     NT8P_BAR();
     NT8P_MFMA(HM, 0, bq0)
     NT8P_BAR();
+    }
     aslot = aslot == 2 ? 0 : aslot + 1; aslot2 = aslot2 == 2 ? 0 : aslot2 + 1;
   }
 #undef NT8P_MFMA
