@@ -1201,6 +1201,28 @@ __device__ __forceinline__ void nt_store8(const NtArgs& g, int64_t gm, int gn, f
   }
 }
 
+// epilogue math of one 8-column group with a residual / pre-activation operand, result packed as bf16 (persistent kernel: the
+// store happens later, see there)
+__device__ __forceinline__ uint4 nt_compute8_aux(const NtArgs& g, float (&v)[8], const float (&b8)[8], const uint4& x4) {
+  const unsigned* xp = (const unsigned*)&x4;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = g.alpha * v[r] + b8[r];
+  if (g.epi == EPI_GELU) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_fast_f(v[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float xa = __uint_as_float(xp[r] << 16), xb = __uint_as_float(xp[r] & 0xffff0000u);
+    if (g.epi == EPI_MUL_GELU_GRAD) { v[2 * r] *= gelu_tanh_grad_fast_f(xa); v[2 * r + 1] *= gelu_tanh_grad_fast_f(xb); }
+    else { v[2 * r] += xa; v[2 * r + 1] += xb; }
+  }
+  uint4 o4; unsigned* op = (unsigned*)&o4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) op[r] = (unsigned)f2bf(v[2 * r]) | ((unsigned)f2bf(v[2 * r + 1]) << 16);
+  return o4;
+}
+
 __device__ __forceinline__ void nt_store4(const NtArgs& g, int64_t gm, int gn, const f32x4& a) {
   if (gm >= g.M || gn >= g.N) return;
   int64_t crow = gm;
@@ -1472,7 +1494,7 @@ static void launch_nt8p(spa3d_ctx* c, const NtArgs& g) {
 // stores too (MI355X_MICROARCH.md "s_waitcnt vmcnt(N)"), so "all but the second K-tile's loads and this epilogue's stores" means
 // the first K-tile has landed while the stores are still draining.  Edge tiles (rows past M) skip stores, so they drain to 0.
 // =================================================================================================================
-template <bool COARSE>
+template <bool COARSE, bool AUX>
 __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
   constexpr int WMT = 8, WNT = 4, BM = 256, BN = 256, NA = 2, NB = 2, HM = 4, HN = 2;
   constexpr int ASLOT = BM * 128, BBUF = BN * 128, BOFF = 3 * ASLOT, NKT = 2 * NA + 2 * NB;
@@ -1637,6 +1659,39 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
       b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w; }
 #pragma unroll
     for (int r = 0; r < 8; ++r) asm volatile("" ::"v"(b8[r]));
+    char* reg = smem + 2 * ASLOT + w * 4096;   // epilogue staging: ring slot 2, wave-private [16 rows][16 chunks of 16 B] f32, chunk ^= row
+    constexpr bool has_aux = AUX;              // residual / pre-activation operand present: bf16 output, no pre_out (host)
+    uint4 held[AUX ? WMT : 1][2];              // aux path: finished rows wait here, in the registers their accumulators vacated
+    if constexpr (has_aux) {
+      // All loads and all math first (aux double-buffered, one pass ahead), stores last: vmcnt retires in order, so a load issued
+      // behind a store would wait for the store's drain, and one issued behind the prologue's LDS-DMA for its latency.
+      uint4 ax[2][2];
+      auto load_ax = [&](int i, uint4 (&dst)[2]) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          int64_t gm = cm0 + (rowl + i * 16 + it * 8);
+          if (gm > g.M - 1) gm = g.M - 1;                      // unconditional load (rows past M re-read the last row, result unused):
+          dst[it] = *(const uint4*)(g.aux + gm * g.ldc + gn);  // straight-line code lets the compiler emit counted waits
+        }
+      };
+      load_ax(0, ax[0]);
+#pragma unroll
+      for (int i = 0; i < WMT; ++i) {
+        if (i + 1 < WMT) load_ax(i + 1, ax[(i + 1) & 1]);
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) *(f32x4*)(reg + fr * 256 + (((j * 4 + fq) ^ fr) << 4)) = acc[i][j];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int row = it * 8 + r8;
+          const f32x4 v0 = *(const f32x4*)(reg + row * 256 + (((2 * c8) ^ row) << 4));
+          const f32x4 v1 = *(const f32x4*)(reg + row * 256 + (((2 * c8 + 1) ^ row) << 4));
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          held[i][it] = nt_compute8_aux(g, v, b8, ax[i & 1][it]);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
     idx = next_valid(idx + nslot);
     const bool more = idx < per_xcd;
     if (more) {
@@ -1644,8 +1699,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
       set_tile(m0, n0);
       prologue();
     }
-    // ---- epilogue out of ring slot 2: wave-private [16 rows][16 chunks of 16 B] f32, chunk ^= row (conflict-free both ways)
-    char* reg = smem + 2 * ASLOT + w * 4096;
+    if constexpr (has_aux) {
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#pragma unroll
+      for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int64_t gm = cm0 + (rowl + i * 16 + it * 8);
+          if (gm < g.M) {
+            u32x4* cp = (u32x4*)((bf16_t*)g.C + gm * g.ldc + gn);
+            const u32x4 o = u32x4{held[i][it].x, held[i][it].y, held[i][it].z, held[i][it].w};
+            if (g.nt_store) __builtin_nontemporal_store(o, cp); else *cp = o;
+          }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < WMT; ++i) {
 #pragma unroll
@@ -1661,6 +1728,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
         if (gm < g.M) nt_store8<true, false>(g, gm, gn, v, b8);
       }
       __builtin_amdgcn_wave_barrier();
+    }
     }
     if (!more) break;
     // the next tile's first K-tile has landed when only its second K-tile and this epilogue's stores can still be outstanding
@@ -1715,13 +1783,18 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   }
   // 8-phase kernels: 256x256 when 256 | N, 128x384 when 384 | N (see the kernel header for the measurements)
   if (c->nt_8p && (d.N % 256 == 0 || d.N % 384 == 0) && (d.M >= 256 * 64 || c->nt_8p == 2) && c->nt_8p != 3) {
-    if (d.N % 256 == 0 && c->nt_8pp && c->nt_8p != 44 && d.K >= 128 && !d.accumulate && !d.aux && d.crow_group == 0 && d.M % 8 == 0) {  // persistent form (accumulate would add loads to the counted wait)
+    if (d.N % 256 == 0 && c->nt_8pp && c->nt_8p != 44 && d.K >= 128 && !d.accumulate && (!d.aux || (c->nt_8pp != 3 && !d.pre_out && !d.out_f32)) && d.crow_group == 0 && d.M % 8 == 0) {  // persistent form (accumulate would add loads to the counted wait)
       NtArgs g2 = g; g2.tiles_m = (int)((g.M + 255) / 256); g2.tiles_n = g.N / 256;
       static bool attrp = false;
-      if (!attrp) { (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840); attrp = true; }
-      if (c->nt_coarse) gemm_nt8pp_kernel<true><<<256, 512, 163840, c->stream>>>(g2);
-      else gemm_nt8pp_kernel<false><<<256, 512, 163840, c->stream>>>(g2);
+      if (!attrp) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        attrp = true;
+      }
+      if (d.aux) gemm_nt8pp_kernel<true, true><<<256, 512, 163840, c->stream>>>(g2);
+      else if (c->nt_coarse) gemm_nt8pp_kernel<true, false><<<256, 512, 163840, c->stream>>>(g2);
+      else gemm_nt8pp_kernel<false, false><<<256, 512, 163840, c->stream>>>(g2);
     } else if (d.N % 256 == 0) { if (c->nt_8p == 44) launch_nt8p<4, 4>(c, g); else launch_nt8p<8, 4>(c, g); } else launch_nt8p<4, 6>(c, g);
     SPA_LAUNCH_CHECK(c);
     return true;
