@@ -1494,9 +1494,9 @@ static void launch_nt8p(spa3d_ctx* c, const NtArgs& g) {
 // stores too (MI355X_MICROARCH.md "s_waitcnt vmcnt(N)"), so "all but the second K-tile's loads and this epilogue's stores" means
 // the first K-tile has landed while the stores are still draining.  Edge tiles (rows past M) skip stores, so they drain to 0.
 // =================================================================================================================
-template <bool COARSE, bool AUX>
+template <int WMT, int WNT, bool COARSE, bool AUX>
 __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
-  constexpr int WMT = 8, WNT = 4, BM = 256, BN = 256, NA = 2, NB = 2, HM = 4, HN = 2;
+  constexpr int BM = 32 * WMT, BN = 64 * WNT, NA = WMT / 4, NB = WNT / 2, HM = WMT / 2, HN = WNT / 2;  // <8,4>: 256x256, <4,6>: 128x384
   constexpr int ASLOT = BM * 128, BBUF = BN * 128, BOFF = 3 * ASLOT, NKT = 2 * NA + 2 * NB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int xcd = blockIdx.x & 7, cu_slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
@@ -1532,7 +1532,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
   int maxgrp = 0;
   auto set_tile = [&](int64_t m0, int n0) {
     baseA = (const char*)(g.A + m0 * g.lda); baseB = (const char*)(g.Bt + (int64_t)n0 * g.ldb);
-    const int64_t mg = g.M - 8 - m0; maxgrp = mg > 255 ? 255 : (mg < 0 ? 0 : (int)mg);
+    const int64_t mg = g.M - 8 - m0; maxgrp = mg > BM - 1 ? BM - 1 : (mg < 0 ? 0 : (int)mg);
   };
   auto stageA = [&](int kt, int slot) {
     char* base = smem + slot * ASLOT;
@@ -1645,49 +1645,72 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
     // ---- residual / pre-activation operand of this tile first (its data is needed first), then the next tile's two K-tiles
     const int64_t cm0 = m0; const int cn0 = n0;
     const bool interior = cm0 + BM <= g.M;
-    const int r8 = lane >> 3, c8 = lane & 7;
-    const int gn = cn0 + wc * 64 + c8 * 8;
-    int rowl = wr * 128 + r8;
-    asm volatile("" : "+v"(rowl));  // opaque per tile: otherwise sixteen 64-bit row addresses are hoisted out of the tile loop and spilled
-    // The epilogue's only load (bias) is issued and consumed HERE, before the next tile's LDS-DMA: vmcnt retires in order and the
-    // compiler does not see the inline-asm LDS-DMA, so a load used after them would be waited for with a count that also covers the
-    // prologue's latency.  GEMMs with a residual / pre-activation operand take the non-persistent kernel (host).
-    float b8[8];
+    // ---- epilogue geometry.  A pass = one 16-row accumulator row-tile i x one column split cs (JW column tiles, <= 64 columns, so the
+    // wave-private f32 image is always [16 rows][16 chunk slots of 16 B] = 4 KiB, chunk ^= row: conflict-free both ways).  Read back as
+    // 8-column groups: item id = 64 it + lane -> row id / NG, group id % NG, valid while id < 16 NG (<4,6>: the second iteration is half full).
+    constexpr int CS = WNT > 4 ? 2 : 1, JW = WNT / CS, NG = 2 * JW, NP = WMT * CS;
+    int prow[2], pg8[2]; bool pval[2];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) b8[r] = 0.f;
-    if (g.bias) { const float4 b0 = *(const float4*)(g.bias + gn), b1 = *(const float4*)(g.bias + gn + 4);
-      b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w; }
+    for (int it = 0; it < 2; ++it) {
+      const int id = it * 64 + lane; pval[it] = id < 16 * NG;
+      const int idc = pval[it] ? id : 0; prow[it] = idc / NG; pg8[it] = idc - prow[it] * NG;
+    }
+    int rbase = wr * (WMT * 16);
+    asm volatile("" : "+v"(rbase));  // opaque per tile: otherwise the per-row 64-bit addresses are hoisted out of the tile loop and spilled
+    auto gn_of = [&](int cs, int it) { return cn0 + wc * (WNT * 16) + cs * (JW * 16) + pg8[it] * 8; };
+    // The epilogue's loads (bias here, the aux operand below) are issued and consumed BEFORE the next tile's LDS-DMA: vmcnt retires in
+    // order and the compiler does not see the inline-asm LDS-DMA, so a load used after them would be waited for with a count that also
+    // covers the prologue's latency.
+    float b8[CS][2][8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) asm volatile("" ::"v"(b8[r]));
-    char* reg = smem + 2 * ASLOT + w * 4096;   // epilogue staging: ring slot 2, wave-private [16 rows][16 chunks of 16 B] f32, chunk ^= row
+    for (int cs = 0; cs < CS; ++cs)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) b8[cs][it][r] = 0.f;
+        if (g.bias) { const int gn = gn_of(cs, it); const float4 b0 = *(const float4*)(g.bias + gn), b1 = *(const float4*)(g.bias + gn + 4);
+          b8[cs][it][0] = b0.x; b8[cs][it][1] = b0.y; b8[cs][it][2] = b0.z; b8[cs][it][3] = b0.w;
+          b8[cs][it][4] = b1.x; b8[cs][it][5] = b1.y; b8[cs][it][6] = b1.z; b8[cs][it][7] = b1.w; }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) asm volatile("" ::"v"(b8[cs][it][r]));
+      }
+    // staging region: ring slot 2 (and, for the 16-KiB slots of <4,6>, the 16 KiB past the B buffers for waves 4-7)
+    char* reg = (ASLOT >= 32768 || w < 4) ? smem + 2 * ASLOT + w * 4096 : smem + 3 * ASLOT + 2 * BBUF + (w - 4) * 4096;
+    auto stage_pass = [&](int i, int cs) {
+#pragma unroll
+      for (int jj = 0; jj < JW; ++jj) *(f32x4*)(reg + fr * 256 + (((jj * 4 + fq) ^ fr) << 4)) = acc[i][cs * JW + jj];
+      __builtin_amdgcn_wave_barrier();  // same wave, LDS is in order: only the compiler must keep the order
+    };
+    auto read_item = [&](int it, float (&v)[8]) {
+      const int row = prow[it];
+      const f32x4 v0 = *(const f32x4*)(reg + row * 256 + (((2 * pg8[it]) ^ row) << 4));
+      const f32x4 v1 = *(const f32x4*)(reg + row * 256 + (((2 * pg8[it] + 1) ^ row) << 4));
+      v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
+    };
     constexpr bool has_aux = AUX;              // residual / pre-activation operand present: bf16 output, no pre_out (host)
-    uint4 held[AUX ? WMT : 1][2];              // aux path: finished rows wait here, in the registers their accumulators vacated
+    uint4 held[AUX ? NP : 1][2];               // aux path: finished rows wait here, in the registers their accumulators vacated
     if constexpr (has_aux) {
       // All loads and all math first (aux double-buffered, one pass ahead), stores last: vmcnt retires in order, so a load issued
       // behind a store would wait for the store's drain, and one issued behind the prologue's LDS-DMA for its latency.
       uint4 ax[2][2];
-      auto load_ax = [&](int i, uint4 (&dst)[2]) {
+      auto load_ax = [&](int p, uint4 (&dst)[2]) {
+        const int i = p / CS, cs = p % CS;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-          int64_t gm = cm0 + (rowl + i * 16 + it * 8);
-          if (gm > g.M - 1) gm = g.M - 1;                      // unconditional load (rows past M re-read the last row, result unused):
-          dst[it] = *(const uint4*)(g.aux + gm * g.ldc + gn);  // straight-line code lets the compiler emit counted waits
+          int64_t gm = cm0 + (rbase + i * 16 + prow[it]);
+          if (gm > g.M - 1) gm = g.M - 1;                                  // unconditional load (rows past M re-read the last row, result
+          dst[it] = *(const uint4*)(g.aux + gm * g.ldc + gn_of(cs, it));    // unused): straight-line code lets the compiler emit counted waits
         }
       };
       load_ax(0, ax[0]);
 #pragma unroll
-      for (int i = 0; i < WMT; ++i) {
-        if (i + 1 < WMT) load_ax(i + 1, ax[(i + 1) & 1]);
-#pragma unroll
-        for (int j = 0; j < WNT; ++j) *(f32x4*)(reg + fr * 256 + (((j * 4 + fq) ^ fr) << 4)) = acc[i][j];
-        __builtin_amdgcn_wave_barrier();
+      for (int p = 0; p < NP; ++p) {
+        if (p + 1 < NP) load_ax(p + 1, ax[(p + 1) & 1]);
+        stage_pass(p / CS, p % CS);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-          const int row = it * 8 + r8;
-          const f32x4 v0 = *(const f32x4*)(reg + row * 256 + (((2 * c8) ^ row) << 4));
-          const f32x4 v1 = *(const f32x4*)(reg + row * 256 + (((2 * c8 + 1) ^ row) << 4));
-          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          held[i][it] = nt_compute8_aux(g, v, b8, ax[i & 1][it]);
+          float v[8]; read_item(it, v);
+          held[p][it] = nt_compute8_aux(g, v, b8[p % CS][it], ax[p & 1][it]);
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -1702,33 +1725,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
     if constexpr (has_aux) {
       typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #pragma unroll
-      for (int i = 0; i < WMT; ++i)
+      for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-          const int64_t gm = cm0 + (rowl + i * 16 + it * 8);
-          if (gm < g.M) {
-            u32x4* cp = (u32x4*)((bf16_t*)g.C + gm * g.ldc + gn);
-            const u32x4 o = u32x4{held[i][it].x, held[i][it].y, held[i][it].z, held[i][it].w};
+          const int64_t gm = cm0 + (rbase + (p / CS) * 16 + prow[it]);
+          if (pval[it] && gm < g.M) {
+            u32x4* cp = (u32x4*)((bf16_t*)g.C + gm * g.ldc + gn_of(p % CS, it));
+            const u32x4 o = u32x4{held[p][it].x, held[p][it].y, held[p][it].z, held[p][it].w};
             if (g.nt_store) __builtin_nontemporal_store(o, cp); else *cp = o;
           }
         }
     } else {
 #pragma unroll
-    for (int i = 0; i < WMT; ++i) {
+      for (int p = 0; p < NP; ++p) {
+        stage_pass(p / CS, p % CS);
 #pragma unroll
-      for (int j = 0; j < WNT; ++j) *(f32x4*)(reg + fr * 256 + (((j * 4 + fq) ^ fr) << 4)) = acc[i][j];
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int row = it * 8 + r8;
-        const f32x4 v0 = *(const f32x4*)(reg + row * 256 + (((2 * c8) ^ row) << 4));
-        const f32x4 v1 = *(const f32x4*)(reg + row * 256 + (((2 * c8 + 1) ^ row) << 4));
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        const int64_t gm = cm0 + (rowl + i * 16 + it * 8);
-        if (gm < g.M) nt_store8<true, false>(g, gm, gn, v, b8);
+        for (int it = 0; it < 2; ++it) {
+          float v[8]; read_item(it, v);
+          const int64_t gm = cm0 + (rbase + (p / CS) * 16 + prow[it]);
+          if (pval[it] && gm < g.M) nt_store8<true, false>(g, gm, gn_of(p % CS, it), v, b8[p % CS][it]);
+        }
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
-    }
     }
     if (!more) break;
     // the next tile's first K-tile has landed when only its second K-tile and this epilogue's stores can still be outstanding
@@ -1783,18 +1801,30 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   }
   // 8-phase kernels: 256x256 when 256 | N, 128x384 when 384 | N (see the kernel header for the measurements)
   if (c->nt_8p && (d.N % 256 == 0 || d.N % 384 == 0) && (d.M >= 256 * 64 || c->nt_8p == 2) && c->nt_8p != 3) {
-    if (d.N % 256 == 0 && c->nt_8pp && c->nt_8p != 44 && d.K >= 128 && !d.accumulate && (!d.aux || (c->nt_8pp != 3 && !d.pre_out && !d.out_f32)) && d.crow_group == 0 && d.M % 8 == 0) {  // persistent form (accumulate would add loads to the counted wait)
+    const bool pers_ok = c->nt_8pp && c->nt_8p != 44 && d.K >= 128 && !d.accumulate && d.crow_group == 0 && d.M % 8 == 0 &&
+                         (!d.aux || (c->nt_8pp != 3 && !d.pre_out && !d.out_f32));
+    if (pers_ok && d.N % 256 == 0) {  // persistent 256x256 (accumulate would add loads to the counted wait)
       NtArgs g2 = g; g2.tiles_m = (int)((g.M + 255) / 256); g2.tiles_n = g.N / 256;
       static bool attrp = false;
       if (!attrp) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<8, 4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<8, 4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<8, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         attrp = true;
       }
-      if (d.aux) gemm_nt8pp_kernel<true, true><<<256, 512, 163840, c->stream>>>(g2);
-      else if (c->nt_coarse) gemm_nt8pp_kernel<true, false><<<256, 512, 163840, c->stream>>>(g2);
-      else gemm_nt8pp_kernel<false, false><<<256, 512, 163840, c->stream>>>(g2);
+      if (d.aux) gemm_nt8pp_kernel<8, 4, true, true><<<256, 512, 163840, c->stream>>>(g2);
+      else if (c->nt_coarse) gemm_nt8pp_kernel<8, 4, true, false><<<256, 512, 163840, c->stream>>>(g2);
+      else gemm_nt8pp_kernel<8, 4, false, false><<<256, 512, 163840, c->stream>>>(g2);
+    } else if (pers_ok && c->nt_8pp == 5 && !d.pre_out && !d.out_f32) {  // persistent 128x384: measured SLOWER than the non-persistent kernel (759 vs 840 TF/s at K = 768: 96-B row segments from the half-width epilogue passes), opt-in via SPA3D_NT_8PP=5
+      NtArgs g2 = g; g2.tiles_m = (int)((g.M + 127) / 128); g2.tiles_n = g.N / 384;
+      static bool attrq = false;
+      if (!attrq) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<4, 6, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<4, 6, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        attrq = true;
+      }
+      if (d.aux) gemm_nt8pp_kernel<4, 6, false, true><<<256, 512, 163840, c->stream>>>(g2);
+      else gemm_nt8pp_kernel<4, 6, false, false><<<256, 512, 163840, c->stream>>>(g2);
     } else if (d.N % 256 == 0) { if (c->nt_8p == 44) launch_nt8p<4, 4>(c, g); else launch_nt8p<8, 4>(c, g); } else launch_nt8p<4, 6>(c, g);
     SPA_LAUNCH_CHECK(c);
     return true;

@@ -391,13 +391,15 @@ def test_linear_tiled_nt_8phase(lib, monkeypatch, M, N, K, act, res, bias):
 
 
 @pytest.mark.parametrize('M,N,K,act,res,bias', [(70001, 512, 256, 0, True, True), (70008, 512, 256, 0, True, True), (140000, 256, 128, 1, False, True), (66000, 768, 384, 0, False, False),
-                                                (4133, 2304, 384, 0, True, False), (256 * 300, 512, 192, 0, True, True), (9000, 1280, 768, 1, False, True)])
+                                                (4133, 2304, 384, 0, True, False), (256 * 300, 512, 192, 0, True, True), (9000, 1280, 768, 1, False, True),
+                                                (70008, 384, 256, 0, True, True), (66000, 1152, 384, 1, False, True), (140000, 384, 128, 0, False, False),
+                                                (65544, 384, 768, 0, True, False), (128 * 700, 384, 1536, 0, False, True)])
 def test_linear_tiled_nt_8phase_persistent(lib, monkeypatch, M, N, K, act, res, bias):
-  """persistent 256x256 8-phase kernel (SPA3D_NT_8PP=1): more tiles than CUs (cross-tile prefetch + counted store wait), ragged
+  """persistent 8-phase kernels (256x256 and 128x384, SPA3D_NT_8PP=1): more tiles than CUs (cross-tile prefetch + counted store wait), ragged
   last M tile (drain path), exact multiples, residual / GELU epilogues"""
   monkeypatch.setenv('SPA3D_NT_RING', '0')
   monkeypatch.setenv('SPA3D_NT_8P', '2')
-  monkeypatch.setenv('SPA3D_NT_8PP', '1')
+  monkeypatch.setenv('SPA3D_NT_8PP', '5')  # 5 = also the (opt-in) persistent 128x384 kernel
   test_linear_tiled_nt(lib, M, N, K, act, res, bias)
 
 

@@ -13,7 +13,8 @@ def run(REPS=40, verbose=True):
   g = torch.Generator(device='cuda').manual_seed(7)
   nt_shapes = [(70000, 512, 256, 0, True), (66048, 768, 384, 1, False), (140000, 256, 128, 0, False), (256 * 700, 2304, 384, 0, False),
                (131072, 1280, 768, 0, True), (99991, 384, 768, 0, True), (65600, 384, 1536, 1, False), (262144, 1536, 384, 1, False),
-               (80000, 1280, 1536, 0, False), (65536, 256, 64, 0, False)]
+               (80000, 1280, 1536, 0, False), (65536, 256, 64, 0, False), (100000, 384, 768, 0, True), (131072, 384, 2304, 0, False),
+               (66000, 1152, 384, 1, False)]
   for (M, N, K, act, res) in nt_shapes:
     A = torch.randn(M, K, device='cuda', generator=g).bfloat16()
     B = (torch.randn(K, N, device='cuda', generator=g) / math.sqrt(K)).bfloat16()
