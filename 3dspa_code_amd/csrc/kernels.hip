@@ -468,10 +468,41 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const float* __restri
     st(out + i, sin_feat(xv, sc.s[f < nf ? f : f - nf], f >= nf));
   }
 }
+// vectorised: 8 consecutive features (one coordinate, one sin/cos half) per thread, one 16-B store, 32-bit index math, the scale table
+// in LDS (indexing the by-value kernel argument per lane went through scratch).  Same arithmetic as sin_feat(): results are identical.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_tokens_vec_kernel(const float* __restrict__ tracks, unsigned nrows, int T_, int nf, float prescale,
+                                                               SinScales sc, T* __restrict__ out, int NC) {
+  constexpr int NV = VecOf<T>::N;
+  __shared__ float ssc[64];
+  if (threadIdx.x < 64) ssc[threadIdx.x] = sc.s[threadIdx.x];
+  __syncthreads();
+  const unsigned W = (unsigned)(NC + 1) * 2u * nf, gpr = W / NV;   // groups per row
+  const unsigned total = nrows * gpr;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const unsigned r = i / gpr; const int j0 = (int)(i - r * gpr) * NV;
+    const int cc = j0 / (2 * nf); const int f0 = j0 - cc * 2 * nf;
+    const bool shifted = f0 >= nf; const int fb = shifted ? f0 - nf : f0;
+    float xv;
+    if (cc < NC) xv = tracks[(int64_t)r * NC + cc];
+    else xv = (float)(int)(r % (unsigned)T_) / (float)T_;  // jnp.arange(T)/T
+    xv = xv / prescale;
+    float o[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) o[e] = sin_feat(xv, ssc[fb + e], shifted);
+    store_vec<T, NV>(out + (int64_t)r * W + j0, o);
+  }
+}
 template <typename T>
 void k_embed_tokens(spa3d_ctx* c, const float* tracks, int64_t nrows, int T_, int nf, float prescale, T* sinbuf, int NC) {
   if (c->dry || nrows == 0) return;
-  embed_tokens_kernel<T><<<GRID1D(nrows * (NC + 1) * 2 * nf, 256), 256, 0, c->stream>>>(tracks, nrows, T_, nf, prescale, make_scales(nf), sinbuf, NC);
+  constexpr int NV = VecOf<T>::N;
+  const int64_t W = (int64_t)(NC + 1) * 2 * nf;
+  if (nf % NV == 0 && nf <= 64 && nrows * (W / NV) < 0x7fffffffLL && nrows < 0x7fffffffLL && (((uintptr_t)sinbuf) & 15) == 0) {
+    embed_tokens_vec_kernel<T><<<GRID1D(nrows * (W / NV), 256), 256, 0, c->stream>>>(tracks, (unsigned)nrows, T_, nf, prescale, make_scales(nf), sinbuf, NC);
+  } else {
+    embed_tokens_kernel<T><<<GRID1D(nrows * W, 256), 256, 0, c->stream>>>(tracks, nrows, T_, nf, prescale, make_scales(nf), sinbuf, NC);
+  }
   SPA_LAUNCH_CHECK(c);
 }
 
