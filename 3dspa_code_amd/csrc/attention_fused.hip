@@ -267,7 +267,6 @@ struct AttnBwdArgs {
   const float *sq, *sk, *km, *lse;
   int S, H; int64_t nprob;
   bf16_t *dq, *dk, *dv; float *dsq, *dsk;
-  int dbg_skip;  // diagnostics only (SPA3D_ATTN_BWD_SKIP): 1 skip the dQ part, 2 skip the dK/dV part; outputs are then wrong
 };
 
 template <int KT>
@@ -341,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs g) {
     __syncthreads();
 
     // ------------------------------------------------------------------ (a) query tiles -> dq
-    for (int qt = w; qt < QT && !(g.dbg_skip & 1); qt += 4) {
+    for (int qt = w; qt < QT; qt += 4) {
       const int q0 = qt * 16;
       // raw q row of this lane's query for the RMSNorm backward: requested NOW so the HBM/L2 latency hides under the MFMAs
       // (the asm "memory" clobbers below pin loads where they are written)
@@ -437,7 +436,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs g) {
     }
 
     // ------------------------------------------------------------------ (b) key tiles -> dk, dv
-    for (int kt = w; kt < QT && !(g.dbg_skip & 2); kt += 4) {  // real key tiles only (S_q == S_k)
+    for (int kt = w; kt < QT; kt += 4) {  // real key tiles only (S_q == S_k)
       const int k0 = kt * 16;
       int krow = k0 + fr; const bool valid = krow < S; if (!valid) krow = S - 1;
       u16x4 xraw[6];  // raw k row for the RMSNorm backward, requested before the MFMA work (see part (a))
@@ -632,7 +631,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
     __syncthreads();
 
     // ------------------------------------------------------------------ (a) query tiles -> dq
-    for (int qt = w; qt < QT && role == 0 && !(g.dbg_skip & 1); qt += 4) {
+    for (int qt = w; qt < QT && role == 0; qt += 4) {
       const int q0 = qt * 16;
       // raw q row of this lane's query for the RMSNorm backward: requested NOW so the HBM/L2 latency hides under the MFMAs
       // (the asm "memory" clobbers below pin loads where they are written)
@@ -731,7 +730,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
     }
 
     // ------------------------------------------------------------------ (b) key tiles -> dk, dv
-    for (int kt = w; kt < QT && role == 1 && !(g.dbg_skip & 2); kt += 4) {  // real key tiles only (S_q == S_k)
+    for (int kt = w; kt < QT && role == 1; kt += 4) {  // real key tiles only (S_q == S_k)
       const int k0 = kt * 16;
       int krow = k0 + fr; const bool valid = krow < S; if (!valid) krow = S - 1;
       u16x4 xraw[6];  // raw k row for the RMSNorm backward, requested before the MFMA work (see part (a))
@@ -873,7 +872,6 @@ bool attn_fused_bwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const b
   if (c->dry) return true;
   AttnBwdArgs a; a.q = q; a.k = k; a.v = v; a.o = o; a.d_o = d_o; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.sq = sq; a.sk = sk; a.km = km;
   a.lse = lse; a.S = Sk; a.H = H; a.nprob = nseq * H; a.dq = dq; a.dk = dk; a.dv = dv; a.dsq = dsq; a.dsk = dsk;
-  { const char* e = getenv("SPA3D_ATTN_BWD_SKIP"); a.dbg_skip = e ? atoi(e) : 0; }
   const int KT = ((Sk + 31) / 32) * 2;
   ProfScope ps(c, PROF_ATTN_BWD, 14.0 * (double)Sq * Sk * Dh * (double)a.nprob, (double)a.nprob * Sq * Dh * 2.0 * 8.0);
   switch (KT) {

@@ -108,12 +108,6 @@ struct spa3d_ctx {
   int hip_err = 0;
   int gemm_impl = 0;  // 0 auto, 1 generic only
   int attn_impl = 0;
-  int nt_astat = 0;   // A-stationary NT kernel for short-K / wide-N shapes: measured SLOWER at 1 wave/SIMD (452 vs 600 TF/s), off;
-                      // SPA3D_NT_ASTAT=1 enables, =2 forces (tests)
-  int nt_persist = 0; // persistent NT kernel with cross-tile prefetch: measured slower (in-order vmcnt ties the next tile's
-                      // loads to the epilogue stores), off; SPA3D_NT_PERSIST=1 enables
-  int nt_astat2 = 0;  // two-team A-stationary NT kernel for K <= 384, N >= 512: 638 TF/s vs 667 for the single-buffer kernel, off;
-                      // SPA3D_NT_ASTAT2=1 enables, =2 forces small M (tests)
   int nt_8p = 1;      // 8-phase kernels (256x256 / 128x384, counted vmcnt, staggered wave rows); 2 = also for small M, 0/3 = off
   int tn_8p = 1;      // 8-phase TN (dW) kernels; SPA3D_TN_8P=0 disables, =2 forces (tests)
   int tn_qp = 2;      // quarters (16 reduction rows) per phase of the 8-phase TN kernels: 2 = 16 MFMAs per barrier pair (+7-10 %), 1 = 8
@@ -121,9 +115,6 @@ struct spa3d_ctx {
   int nt_8pp = 1;     // persistent form of the 256x256 8-phase NT kernel (SPA3D_NT_8PP=0 disables): +3-6 %
   int nt_coarse = 1;  // persistent NT kernel with two phases per K-tile (32 MFMAs per barrier pair) instead of four (SPA3D_NT_COARSE)
   int nt_stream = 1;  // non-temporal stores for bf16 GEMM outputs >= 512 MB (SPA3D_NT_STREAM=0 disables)
-  int nt_ring = 0;    // persistent 256x128 kernels, measured SLOWER than the 128x128 ones (500-740 vs 660-885 TF/s), off:
-                      // SPA3D_NT_RING=1 ping-pong teams (staggered by one barrier), =3 plain ring; =2 ping-pong forced for small M (tests)
-  int nt_256 = 1;     // 256x256 8-wave NT kernel for N % 256 == 0 (SPA3D_NT_256=0 disables; =2 forces small M in tests)
   int nt_occ = 1;     // single-buffer 4-workgroups/CU NT kernel for K <= 512 (SPA3D_NT_OCC=0 disables)
   bool tn_colsum_fused = false;  // set by gemm_tn_bf16: the last call also produced GemmDesc::colsum_out
   Prof prof;

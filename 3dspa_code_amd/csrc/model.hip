@@ -724,11 +724,7 @@ int spa3d_create(const spa3d_config* cfg, spa3d_handle* out) {
   build_leaves(c);
   const char* e = getenv("SPA3D_GEMM_IMPL"); if (e) c->gemm_impl = atoi(e);
   e = getenv("SPA3D_ATTN_IMPL"); if (e) c->attn_impl = atoi(e);
-  e = getenv("SPA3D_NT_ASTAT"); if (e) c->nt_astat = atoi(e);
-  e = getenv("SPA3D_NT_PERSIST"); if (e) c->nt_persist = atoi(e);
   e = getenv("SPA3D_NT_OCC"); if (e) c->nt_occ = atoi(e);
-  e = getenv("SPA3D_NT_256"); if (e) c->nt_256 = atoi(e);
-  e = getenv("SPA3D_NT_RING"); if (e) c->nt_ring = atoi(e);
   e = getenv("SPA3D_NT_8P"); if (e) c->nt_8p = atoi(e);
   e = getenv("SPA3D_NT_8PP"); if (e) c->nt_8pp = atoi(e);
   e = getenv("SPA3D_NT_COARSE"); if (e) c->nt_coarse = atoi(e);
@@ -736,7 +732,6 @@ int spa3d_create(const spa3d_config* cfg, spa3d_handle* out) {
   e = getenv("SPA3D_TN_8P"); if (e) c->tn_8p = atoi(e);
   e = getenv("SPA3D_TN_QP"); if (e) c->tn_qp = atoi(e);
   e = getenv("SPA3D_TN_ROUNDS"); if (e) c->tn_rounds = atoi(e);
-  e = getenv("SPA3D_NT_ASTAT2"); if (e) c->nt_astat2 = atoi(e);
   *out = c;
   return SPA3D_OK;
 }

@@ -9,11 +9,7 @@ namespace {
 struct OpCtx : spa3d_ctx {
   OpCtx(void* stream_, void* ws, int64_t ws_bytes) {
     stream = (hipStream_t)stream_; ar.base = (char*)ws; ar.cap = ws_bytes;
-    const char* e = getenv("SPA3D_NT_ASTAT"); if (e) nt_astat = atoi(e);
-    e = getenv("SPA3D_NT_PERSIST"); if (e) nt_persist = atoi(e);
-    e = getenv("SPA3D_NT_OCC"); if (e) nt_occ = atoi(e);
-    e = getenv("SPA3D_NT_256"); if (e) nt_256 = atoi(e);
-    e = getenv("SPA3D_NT_RING"); if (e) nt_ring = atoi(e);
+    const char* e = getenv("SPA3D_NT_OCC"); if (e) nt_occ = atoi(e);
     e = getenv("SPA3D_NT_8P"); if (e) nt_8p = atoi(e);
     e = getenv("SPA3D_NT_8PP"); if (e) nt_8pp = atoi(e);
     e = getenv("SPA3D_NT_COARSE"); if (e) nt_coarse = atoi(e);
@@ -21,7 +17,6 @@ struct OpCtx : spa3d_ctx {
     e = getenv("SPA3D_TN_8P"); if (e) tn_8p = atoi(e);
     e = getenv("SPA3D_TN_QP"); if (e) tn_qp = atoi(e);
     e = getenv("SPA3D_TN_ROUNDS"); if (e) tn_rounds = atoi(e);
-    e = getenv("SPA3D_NT_ASTAT2"); if (e) nt_astat2 = atoi(e);
   }
   template <typename U> U* alloc(int64_t n) { return (U*)ar.alloc(n * (int64_t)sizeof(U)); }
   int status() { return ar.overflow ? SPA3D_ERR_WORKSPACE : (hip_err ? SPA3D_ERR_HIP : SPA3D_OK); }

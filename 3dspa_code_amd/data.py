@@ -125,8 +125,17 @@ def load_checkpoint(checkpoint_path: str, model=None, allow_pickle: bool = False
   return params
 
 
-def load_train_state(checkpoint_path: str, state):
-  """Resume: parameters, Adam moments and step back into a TrainState (in place)."""
+def load_train_state(checkpoint_path: str, state, rank0_only: bool = False):
+  """Resume: parameters, Adam moments and step back into a TrainState (in place).  Under data parallelism every replica ends
+  with rank 0's state: with `rank0_only` only rank 0 reads the file and the buffers + step are broadcast."""
+  import torch.distributed as dist
+  multi = dist.is_available() and dist.is_initialized() and state.world > 1
+  if multi and rank0_only and state.rank != 0:
+    step = torch.zeros(1, dtype=torch.int64, device=state.flat.device)
+    state.sync_from_rank0()
+    dist.broadcast(step, src=0, group=state.pg)
+    state.step = int(step.item())
+    return state
   data = np.load(checkpoint_path, allow_pickle=False)
   model = state.model
   dims = model._dims_from_params(state.params)
@@ -142,4 +151,8 @@ def load_train_state(checkpoint_path: str, state):
         raise ValueError(f'shape mismatch for {key}: expected {shape}, got {a.shape}')
       buf[off:off + n] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).reshape(-1).to(buf.device)
   state.step = int(data['step'])
+  if multi:
+    state.sync_from_rank0()
+    if rank0_only:
+      dist.broadcast(torch.tensor([state.step], dtype=torch.int64, device=state.flat.device), src=0, group=state.pg)
   return state

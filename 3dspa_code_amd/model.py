@@ -312,8 +312,8 @@ class TrackAutoEncoder3D:
     want = lib.spa3d_workspace_bytes(h, B, max(N, 1), Q, max(T, 1), B, 1 if train else 0)
     floor = lib.spa3d_workspace_bytes(h, B, max(N, 1), Q, max(T, 1), 1, 1 if train else 0)
     have = self._ws.numel() if (self._ws is not None and self._ws.device == torch.device(device)) else 0
-    if have >= want or (have >= floor and have >= self._ws_cap):
-      return self._ws  # big enough for the whole batch, or already as large as the memory budget allowed
+    if have >= want or (self._ws_cap > 0 and have >= max(floor, self._ws_cap)):
+      return self._ws  # big enough for the whole batch, or a budget cap was hit before and this is already that large
     free, _total = torch.cuda.mem_get_info(device)
     budget = int((free + have) * self.workspace_fraction)
     size = min(want, max(budget, floor))

@@ -32,7 +32,8 @@ def create_learning_rate_schedule(base_lr: float, warmup_steps: int, total_steps
 
 def global_visible_count(visible: torch.Tensor, group=None) -> float:
   """max(sum(query_tracks_visible) over ALL ranks, 1): both loss terms divide by the batch-global visible count
-  (train.py:111-113,119-121), so under data parallelism it is one scalar all-reduce BEFORE the backward."""
+  (train.py:111-113,119-121), so under data parallelism it is one scalar all-reduce BEFORE the backward.  The C-ABI takes the
+  denominator by value, so this is one 4-byte device->host read per step (the only host sync of the multi-GPU step)."""
   s = visible.to(torch.float32).sum()
   if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
     dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
@@ -54,13 +55,36 @@ def allreduce_flat_(flat: torch.Tensor, bucket_elems: int, group=None, extra=())
     w.wait()
 
 
+def broadcast_state_(tensors, src: int = 0, group=None):
+  """Replicas must start from rank `src`'s parameters and Adam moments whatever each rank initialised or loaded
+  (a checkpoint read on rank 0 only, different seeds): one broadcast per buffer at construction / resume."""
+  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    return
+  for t in tensors:
+    dist.broadcast(t, src=src, group=group)
+
+
+def _hip_uniform_noise(n: int, device) -> torch.Tensor:
+  out = torch.empty(n, dtype=torch.float32, device=device)
+  _lib.check(_lib.load().spa3d_uniform_noise(out.data_ptr(), n, 0, 0, _stream(out)), what='spa3d_uniform_noise')
+  return out
+
+
 class TrainState:
-  """create_model_state + train_step of train.py:132-187,217-260 for model_type='3dspa'."""
+  """create_model_state + train_step of train.py:132-187,217-260 for model_type='3dspa'.
+
+  `compute`, `adamw` and `noise_fn` default to the HIP library (there is no CPU fallback); they are injectable so that the
+  host logic of the data-parallel step -- denominator pre-reduce, rank slice of the global discretisation noise, bucketed
+  SUM all-reduce, clip + AdamW on reduced gradients, rank-0 broadcast -- can be driven at world size 2 over gloo on CPU
+  (tests/test_dp_gloo.py) with a stand-in compute.
+    compute(params_tree, batch, grads_flat, denom, discretize, noise) -> {'total_loss','position_loss','visible_loss'}
+    adamw(flat, grads, m, v, lr, step, clip, b1, b2, eps, wd, scratch) -> None  (scratch[0] := global grad norm)
+    noise_fn(n, device) -> float32[n] = jax.random.uniform(PRNGKey(0), [n]) (track_autoencoder_3d.py:254-257)"""
 
   def __init__(self, model: TrackAutoEncoder3D, params, learning_rate: float = 1e-4, warmup_steps: int = 10000,
                total_steps: int = 1000000, weight_decay: float = 0.01, clip_norm: float = 1.0, b1: float = 0.9,
                b2: float = 0.999, eps: float = 1e-8, process_group: Optional[dist.ProcessGroup] = None,
-               grad_bucket_bytes: int = 128 << 20):
+               grad_bucket_bytes: int = 128 << 20, compute=None, adamw=None, noise_fn=None):
     self.model = model
     self.params = params if hasattr(params, 'flat') and params.flat is not None else None
     flat = model.flat_from_tree(params)
@@ -76,21 +100,52 @@ class TrainState:
     self.schedule = create_learning_rate_schedule(learning_rate, warmup_steps, total_steps)
     self.wd, self.clip, self.b1, self.b2, self.eps = weight_decay, clip_norm, b1, b2, eps
     self.pg = process_group
-    self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+    on = dist.is_available() and dist.is_initialized()
+    self.world = dist.get_world_size(process_group) if on else 1
+    self.rank = dist.get_rank(process_group) if on else 0
     self.bucket_elems = max(1, grad_bucket_bytes // 4)
+    self._compute = compute or self._hip_compute
+    self._adamw = adamw or self._hip_adamw
+    self._noise_fn = noise_fn or _hip_uniform_noise
+    self._noise_cache = {}
+    self.sync_from_rank0()
+
+  def sync_from_rank0(self):
+    """parameters + Adam moments of every replica := rank 0's (also after load_train_state on rank 0 only)"""
+    broadcast_state_((self.flat, self.m, self.v), 0, self.pg)
+
+  # ---- default (HIP) compute and optimizer
+  def _hip_compute(self, params, batch, grads_flat, denom, discretize, noise):
+    ld, _, _ = self.model.loss_and_grads(params, batch, grads_flat=grads_flat, accumulate=False, denom=denom,
+                                         discretize=discretize, noise=noise)
+    return ld
+
+  def _hip_adamw(self, flat, grads, m, v, lr, step, clip, b1, b2, eps, wd, scratch):
+    _lib.check(_lib.load().spa3d_adamw_step(flat.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(), flat.numel(), lr, step,
+                                            clip, b1, b2, eps, wd, scratch.data_ptr(), _stream(flat)), what='spa3d_adamw_step')
+
+  def rank_noise(self, b_local: int):
+    """The reference draws uniform(PRNGKey(0), [B_global, L, Ld]) over the GLOBAL batch (3d:254-258); rank r owns rows
+    r*B_local .. of that tensor, not a draw of its own over [B_local, L, Ld].  Fixed key => drawn once and cached."""
+    key = (b_local, self.world, self.rank)
+    if key not in self._noise_cache:
+      L, Ld = self.model.num_latent_tokens, self.model.latent_token_dim
+      full = self._noise_fn(b_local * self.world * L * Ld, self.flat.device).view(self.world, b_local, L, Ld)
+      self._noise_cache = {key: full[self.rank].clone()}
+    return self._noise_cache[key]
 
   def train_step(self, batch, discretize: bool = True, noise=None):
     denom = global_visible_count(batch['query_tracks_visible'], self.pg) if self.world > 1 else 0.0
-    ld, _, _ = self.model.loss_and_grads(self.params, batch, grads_flat=self.grads, accumulate=False, denom=denom,
-                                         discretize=discretize, noise=noise)
-    l3 = torch.stack([ld['total_loss'], ld['position_loss'], ld['visible_loss']])
+    if self.world > 1 and discretize and noise is None:
+      noise = self.rank_noise(batch['query_tracks_visible'].shape[0])
+    ld = self._compute(self.params, batch, self.grads, denom, discretize, noise)
+    l3 = torch.stack([torch.as_tensor(ld[k], dtype=torch.float32, device=self.flat.device).reshape(())
+                      for k in ('total_loss', 'position_loss', 'visible_loss')])
     # the per-rank gradients and loss terms already carry the global 1/denominator -> plain SUM over ranks
     allreduce_flat_(self.grads, self.bucket_elems, self.pg, extra=(l3,))
     lr = self.schedule(self.step)
-    _lib.check(_lib.load().spa3d_adamw_step(self.flat.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                                            self.flat.numel(), lr, self.step, self.clip, self.b1, self.b2, self.eps, self.wd,
-                                            self.scratch.data_ptr(), _stream(self.flat)), what='spa3d_adamw_step')
+    self._adamw(self.flat, self.grads, self.m, self.v, lr, self.step, self.clip, self.b1, self.b2, self.eps, self.wd, self.scratch)
     self.step += 1
-    # metric keys of train.py:180-185 (device scalars: no host sync in the step)
+    # metric keys of train.py:180-185 (device scalars)
     return {'train/loss': l3[0], 'train/position_loss': l3[1], 'train/visible_loss': l3[2], 'train/learning_rate': lr,
             'train/grad_norm': self.scratch[0]}

@@ -2,7 +2,9 @@
 the batch shards over ranks, the loss denominator is the GLOBAL visible count (one scalar all-reduce before the
 backward, train.py:111-113), gradients are SUM-all-reduced in buckets, and the result equals the single-process
 gradient of the whole batch.  The oracle plays the compute kernel here (no GPU in this container); the collectives
-and their host logic are the product's (3dspa_code_amd/train.py)."""
+and their host logic are the product's (3dspa_code_amd/train.py).  test_trainstate_step_world2_equals_full_batch drives
+TrainState.train_step ITSELF (world > 1 branch: denominator pre-reduce, rank slice of the global discretisation noise,
+bucketed SUM all-reduce, clip + AdamW, rank-0 broadcast at construction) with the oracle injected as compute / AdamW."""
 import os
 import socket
 
@@ -80,3 +82,97 @@ def test_local_denominator_would_be_wrong():
   halves = [float(O.compute_loss_3d(m(params, {k: v[i:i + 2] for k, v in batch.items()}, discretize=False),
                                     {k: v[i:i + 2] for k, v in batch.items()})['total_loss']) for i in (0, 2)]
   assert abs(sum(halves) / 2 - full) > 1e-3 * abs(full)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# TrainState.train_step at world size 2 (the product's host logic end to end, compute injected)
+# ---------------------------------------------------------------------------------------------------------------------
+def _oracle_hooks(cfg, names_shapes):
+  """compute / adamw / noise_fn stand-ins with the signatures TrainState documents (oracle = checker-side code only)."""
+  import numpy as np
+  from oracle import np_blocks as NB
+  m = O.TrackAutoEncoder3D(cfg)
+
+  def to_tree(flat_tree):
+    return O.tree_unflatten({k: v.double() for k, v in O.tree_flatten(flat_tree).items()})
+
+  def compute(params, batch, grads_flat, denom, discretize, noise):
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    ld, _, g = O.loss_and_grads(m, to_tree(params), b64, discretize=discretize, noise=None if noise is None else noise.double(),
+                                denom=denom if denom > 0 else None)
+    for name, shape, off in names_shapes:
+      n = int(np.prod(shape))
+      grads_flat[off:off + n] = g[name].reshape(-1).float()
+    return ld
+
+  def adamw(flat, grads, mm, vv, lr, step, clip, b1, b2, eps, wd, scratch):
+    gn = O.adamw_step({'p': flat}, {'p': grads}, {'p': mm}, {'p': vv}, step, lr, clip=clip, wd=wd, b1=b1, b2=b2, eps=eps)
+    scratch[0] = gn
+
+  def noise_fn(n, device):
+    return torch.from_numpy(NB.jax_uniform_legacy((n,), (0, 0)).astype(np.float32)).to(device)
+
+  return compute, adamw, noise_fn
+
+
+def _ts_worker(rank, world, port, q):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    import spa3d
+    from util import product_model
+    torch.set_num_threads(2)
+    cfg = O.Config(**MINI, use_dino=False, use_depth=False)
+    B = 4
+    batch = O.synthetic_batch(B, 5, 4, 8, seed=17)
+    batch['query_tracks_visible'][0] = 0
+    model = product_model(spa3d, cfg, 'fp32')  # host object only: handle creation + leaf table run without a GPU
+    # every rank starts from DIFFERENT parameters: construction must broadcast rank 0's
+    params = O.init_params(cfg, seed=5 + rank, dtype=torch.float32, with_dino=False, with_depth=False, perturb=0.1)
+    _, leaves, n = model._handle(0, 0)
+    compute, adamw, noise_fn = _oracle_hooks(cfg, leaves)
+    st = spa3d.TrainState(model, params, learning_rate=1e-2, warmup_steps=1, total_steps=10, grad_bucket_bytes=4000, compute=compute,
+                          adamw=adamw, noise_fn=noise_fn)
+    ref0 = model.flat_from_tree(O.init_params(cfg, seed=5, dtype=torch.float32, with_dino=False, with_depth=False, perturb=0.1))
+    bcast_ok = bool(torch.equal(st.flat, ref0))
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    shard = {k: v[lo:hi] for k, v in batch.items()}
+    outs = [st.train_step(shard) for _ in range(2)]  # noise=None: the rank slice of the global PRNGKey(0) draw
+    if rank == 0:
+      # single-process reference: the same TrainState code at world 1 semantics, full batch, global noise
+      c1, a1, n1 = _oracle_hooks(cfg, leaves)
+      flat = ref0.clone(); mm = torch.zeros_like(flat); vv = torch.zeros_like(flat); g = torch.zeros_like(flat); sc = torch.zeros(4)
+      sched = spa3d.create_learning_rate_schedule(1e-2, 1, 10)
+      full_noise = n1(B * cfg.num_latent_tokens * cfg.latent_token_dim, 'cpu').view(B, cfg.num_latent_tokens, cfg.latent_token_dim)
+      losses = []
+      for step in range(2):
+        ld = c1(model.tree_from_flat(flat, 0, 0), batch, g, 0.0, True, full_noise)
+        losses.append(float(ld['total_loss']))
+        a1(flat, g, mm, vv, sched(step), step, 1.0, 0.9, 0.999, 1e-8, 0.01, sc)
+      q.put((bcast_ok, float((st.flat - flat).abs().max()), [float(o['train/loss']) for o in outs], losses,
+             float(outs[-1]['train/grad_norm']), float(sc[0])))
+    else:
+      q.put((bcast_ok,))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_trainstate_step_world2_equals_full_batch():
+  ctx = mp.get_context('spawn')
+  q = ctx.SimpleQueue()
+  port = _free_port()
+  procs = [ctx.Process(target=_ts_worker, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = [q.get(), q.get()]
+  for p in procs:
+    p.join(300)
+    assert p.exitcode == 0
+  full = next(r for r in res if len(r) > 1)
+  assert all(r[0] for r in res), 'rank-0 parameter broadcast at construction'
+  _, perr, losses, ref_losses, gn, gn_ref = full
+  assert perr < 2e-6, perr  # two AdamW steps on fp32 buffers; gradients differ only by summation order
+  for a, b in zip(losses, ref_losses):
+    assert abs(a - b) < 1e-5 * abs(b)
+  assert abs(gn - gn_ref) < 1e-4 * gn_ref

@@ -351,28 +351,9 @@ def test_attention_fused_fwd_bwd(lib, nseq, S, H, masked):
   assert max(errs) < 3e-2
 
 
-@pytest.mark.parametrize('M,N,K,act,res,bias', [(4133, 2304, 384, 0, False, False), (1000, 1536, 384, 1, False, True),
-                                                (2050, 768, 256, 0, True, True), (700, 384, 128, 0, False, True)])
-def test_linear_tiled_nt_a_stationary(lib, monkeypatch, M, N, K, act, res, bias):
-  """the A-stationary variant (short K, wide N), forced on for small M with SPA3D_NT_ASTAT=2"""
-  monkeypatch.setenv('SPA3D_NT_RING', '0')
-  monkeypatch.setenv('SPA3D_NT_ASTAT', '2')
-  test_linear_tiled_nt(lib, M, N, K, act, res, bias)
-
-
-@pytest.mark.parametrize('M,N,K,act,res,bias', [(40000, 1536, 384, 1, False, True), (70001, 384, 768, 0, True, True), (33000, 2304, 128, 0, False, False)])
-def test_linear_tiled_nt_persistent(lib, monkeypatch, M, N, K, act, res, bias):
-  """>= 2048 output tiles: the (experimental, default-off) persistent kernel with cross-tile prefetch"""
-  monkeypatch.setenv('SPA3D_NT_RING', '0')
-  monkeypatch.setenv('SPA3D_NT_PERSIST', '1')
-  monkeypatch.setenv('SPA3D_NT_OCC', '0')
-  test_linear_tiled_nt(lib, M, N, K, act, res, bias)
-
-
 @pytest.mark.parametrize('M,N,K,act,res,bias', [(1000, 384, 256, 0, False, True), (4133, 2304, 384, 0, False, False), (2050, 384, 1536, 0, True, True)])
 def test_linear_tiled_nt_double_buffered(lib, monkeypatch, M, N, K, act, res, bias):
   """the 2-buffer kernel with the LDS-staged epilogue also on the short-K shapes the single-buffer kernel normally takes"""
-  monkeypatch.setenv('SPA3D_NT_RING', '0')
   monkeypatch.setenv('SPA3D_NT_OCC', '0')
   test_linear_tiled_nt(lib, M, N, K, act, res, bias)
 
@@ -385,7 +366,6 @@ def test_linear_tiled_nt_double_buffered(lib, monkeypatch, M, N, K, act, res, bi
 def test_linear_tiled_nt_8phase(lib, monkeypatch, M, N, K, act, res, bias):
   """the 8-phase kernels (256x256 when 256 | N, 128x384 when 384 | N; counted vmcnt, staggered wave rows), forced on for any M with SPA3D_NT_8P=2;
   K = 64 / 128 / 192 exercise the prologue and tail paths of the schedule (1, 2, 3 K-tiles)"""
-  monkeypatch.setenv('SPA3D_NT_RING', '0')
   monkeypatch.setenv('SPA3D_NT_8P', '2')
   test_linear_tiled_nt(lib, M, N, K, act, res, bias)
 
@@ -397,28 +377,8 @@ def test_linear_tiled_nt_8phase(lib, monkeypatch, M, N, K, act, res, bias):
 def test_linear_tiled_nt_8phase_persistent(lib, monkeypatch, M, N, K, act, res, bias):
   """persistent 8-phase kernels (256x256 and 128x384, SPA3D_NT_8PP=1): more tiles than CUs (cross-tile prefetch + counted store wait), ragged
   last M tile (drain path), exact multiples, residual / GELU epilogues"""
-  monkeypatch.setenv('SPA3D_NT_RING', '0')
   monkeypatch.setenv('SPA3D_NT_8P', '2')
   monkeypatch.setenv('SPA3D_NT_8PP', '5')  # 5 = also the (opt-in) persistent 128x384 kernel
-  test_linear_tiled_nt(lib, M, N, K, act, res, bias)
-
-
-@pytest.mark.parametrize('M,N,K,act,res,bias', [(4133, 2304, 384, 0, False, False), (1000, 1536, 384, 1, False, True),
-                                                (2050, 768, 256, 0, True, True), (700, 1280, 1536, 0, False, True), (300, 256, 64, 0, False, False)])
-def test_linear_tiled_nt_256(lib, monkeypatch, M, N, K, act, res, bias):
-  """the 256x256 8-wave kernel (N % 256 == 0), forced on for small M with SPA3D_NT_256=2"""
-  monkeypatch.setenv('SPA3D_NT_RING', '0')
-  monkeypatch.setenv('SPA3D_NT_256', '2')
-  test_linear_tiled_nt(lib, M, N, K, act, res, bias)
-
-
-@pytest.mark.parametrize('M,N,K,act,res,bias', [(4133, 2304, 384, 0, False, False), (1000, 1536, 384, 1, False, True),
-                                                (2050, 768, 256, 0, True, True), (700, 640, 128, 0, False, True)])
-def test_linear_tiled_nt_a_stationary_two_teams(lib, monkeypatch, M, N, K, act, res, bias):
-  """two 4-wave teams sharing one resident A panel (odd and even column-tile counts), forced on for small M"""
-  monkeypatch.setenv('SPA3D_NT_RING', '0')
-  monkeypatch.setenv('SPA3D_NT_ASTAT2', '2')
-  monkeypatch.setenv('SPA3D_NT_256', '0')
   test_linear_tiled_nt(lib, M, N, K, act, res, bias)
 
 
@@ -458,14 +418,3 @@ def test_attention_fully_masked_sequence(lib, dtype, impl):
   assert float(dqkv[1, :, :2 * E].float().abs().max()) == 0.0
   assert rel_err(dqkv[..., :E].float(), qr.grad) < tol and rel_err(dqkv[..., E:2 * E].float(), kr.grad) < tol
   assert rel_err(dqkv[..., 2 * E:].float(), vr.grad) < tol
-
-
-@pytest.mark.parametrize('M,N,K,act,res,bias', [(4133, 2304, 384, 0, False, False), (1000, 1536, 384, 1, False, True),
-                                                (2050, 384, 1536, 0, True, True), (700, 1280, 768, 0, False, True),
-                                                (300, 128, 64, 0, False, False), (70001, 384, 768, 0, True, True)])
-@pytest.mark.parametrize('variant', ['2', '4'])
-def test_linear_tiled_nt_ring(lib, monkeypatch, variant, M, N, K, act, res, bias):
-  """persistent 256x128 kernels (counted vmcnt, steps flattened over tiles; default-off experiments): '2' = ping-pong teams
-  staggered by one barrier, '4' = plain ring; forced on for small M"""
-  monkeypatch.setenv('SPA3D_NT_RING', variant)
-  test_linear_tiled_nt(lib, M, N, K, act, res, bias)
