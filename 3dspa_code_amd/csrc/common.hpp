@@ -13,6 +13,9 @@ __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsig
 // round-to-nearest-even; a plain cast emits v_cvt_pk_bf16_f32 and keeps NaN a NaN
 // (MI355X_MICROARCH.md "Correctness boundaries")
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+// the 16-bit activation type's MFMA operand vector and instruction (8 elements per lane, 16x16x32)
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma16x8;
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 template <typename T> __device__ __forceinline__ float ld(const T* p);
 template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf2f(*p); }
@@ -85,7 +88,8 @@ struct Arena {  // bump allocator over the caller's workspace; dry mode only cou
 };
 
 // live per-kernel-class timing with HIP events on the launch stream (bench.py "roofline"; off by default)
-enum { PROF_GEMM_NT = 0, PROF_GEMM_TN = 1, PROF_GEMM_GENERIC = 2, PROF_ATTN_FWD = 3, PROF_ATTN_BWD = 4, PROF_NCLS = 5 };
+enum { PROF_GEMM_NT = 0, PROF_GEMM_TN = 1, PROF_GEMM_GENERIC = 2, PROF_ATTN_FWD = 3, PROF_ATTN_BWD = 4, PROF_LN_FWD = 5, PROF_LN_BWD = 6,
+       PROF_ATTN_Q1 = 7, PROF_NCLS = 8 };
 struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; int64_t tag[4] = {0, 0, 0, 0}; };  // tag: M, N, K, flags (GEMMs)
 struct Prof {
   bool on = false;
@@ -108,6 +112,7 @@ struct spa3d_ctx {
   int hip_err = 0;
   int gemm_impl = 0;  // 0 auto, 1 generic only
   int attn_impl = 0;
+  int attn_bwd_mode = 0;  // fused attention backward structure: 0 auto, 1 four images + concurrent roles, 2 split-pass 4 waves (2 WG/CU), 3 split-pass 8 waves
   int nt_8p = 1;      // 8-phase kernels (256x256 / 128x384, counted vmcnt, staggered wave rows); 2 = also for small M, 0/3 = off
   int tn_8p = 1;      // 8-phase TN (dW) kernels; SPA3D_TN_8P=0 disables, =2 forces (tests)
   int tn_qp = 2;      // quarters (16 reduction rows) per phase of the 8-phase TN kernels: 2 = 16 MFMAs per barrier pair (+7-10 %), 1 = 8

@@ -174,6 +174,8 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const T* __restrict__ x
 template <typename T>
 void k_layernorm(spa3d_ctx* c, const T* x, const float* scale, T* y, float* stats, int64_t rows, int d) {
   if (c->dry || rows == 0) return;
+  ProfScope ps(c, PROF_LN_FWD, 8.0 * (double)rows * d, (double)rows * d * 2.0 * sizeof(T) + rows * 8.0);  // read x, write y (+ stats)
+  ps.tag(rows, d, 0, 0);
   constexpr int NV = VecOf<T>::N;
   const bool al = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
   if (d % NV == 0 && al && d <= 64 * NV * 4) {
@@ -260,6 +262,8 @@ template <typename T>
 void k_layernorm_bwd(spa3d_ctx* c, const T* x, const float* scale, const float* stats, const T* dy, T* dx, float* dscale,
                      int64_t rows, int d, const T* add) {
   if (c->dry || rows == 0) return;
+  ProfScope ps(c, PROF_LN_BWD, 16.0 * (double)rows * d, (double)rows * d * (add ? 4.0 : 3.0) * sizeof(T) + rows * 8.0);  // x, dy, (add), dx
+  ps.tag(rows, d, add ? 1 : 0, 0);
   static int gcapb = -1; if (gcapb < 0) { const char* e = getenv("SPA3D_LNB_GRID"); gcapb = e ? atoi(e) : 1024; }
   unsigned g = (unsigned)std::min<int64_t>(cdiv(rows, 4), d <= 512 ? gcapb : 2 * gcapb);  // measured: 1024 blocks at d = 384, 2048 at d = 1280
   constexpr int NV = VecOf<T>::N;
@@ -1419,6 +1423,8 @@ void k_attn_q1_fwd(spa3d_ctx* c, const T* q0, int64_t ldq0, const T* k, const T*
   if (c->dry || nseq == 0) return;
   if (S > Q1_MAXS || Dh % 4 || Dh > 128) { if (!c->hip_err) { c->hip_err = -3; c->err = "attn_q1: S <= 320 and Dh % 4 == 0, Dh <= 128 required"; } return; }
   const int64_t nprob = nseq * H;
+  ProfScope ps(c, PROF_ATTN_Q1, 4.0 * (double)nprob * S * Dh, (double)nprob * S * Dh * 2.0 * sizeof(T) + (double)nprob * S * 4.0);  // K, V once (+ p0)
+  ps.tag(nseq, S, H, 0);
   unsigned g = (unsigned)std::min<int64_t>(cdiv(nprob, 4), 8192);
   constexpr int NV = VecOf<T>::N;
   const int vec = (Dh % (4 * NV) == 0 && ldk % NV == 0 && ldv % NV == 0 && ldq0 % NV == 0 &&
@@ -1571,6 +1577,8 @@ void k_attn_q1_bwd(spa3d_ctx* c, const T* q0, int64_t ldq0, const T* k, const T*
   if (c->dry || nseq == 0) return;
   if (S > Q1_MAXS || Dh % 4 || Dh > 128) { if (!c->hip_err) { c->hip_err = -3; c->err = "attn_q1: S <= 320 and Dh % 4 == 0, Dh <= 128 required"; } return; }
   const int64_t nprob = nseq * H;
+  ProfScope ps(c, PROF_ATTN_Q1, 8.0 * (double)nprob * S * Dh, (double)nprob * S * Dh * 4.0 * sizeof(T) + (double)nprob * S * 4.0);  // K, V read; dK, dV written
+  ps.tag(nseq, S, H, 1);
   unsigned g = (unsigned)std::min<int64_t>(cdiv(nprob, 4), 4096);
   constexpr int NV = VecOf<T>::N;
   const int vec = (Dh % (4 * NV) == 0 && ldk % NV == 0 && ldv % NV == 0 && ldq0 % NV == 0 &&

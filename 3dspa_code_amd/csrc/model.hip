@@ -724,6 +724,7 @@ int spa3d_create(const spa3d_config* cfg, spa3d_handle* out) {
   build_leaves(c);
   const char* e = getenv("SPA3D_GEMM_IMPL"); if (e) c->gemm_impl = atoi(e);
   e = getenv("SPA3D_ATTN_IMPL"); if (e) c->attn_impl = atoi(e);
+  e = getenv("SPA3D_ATTN_BWD_MODE"); if (e) c->attn_bwd_mode = atoi(e);
   e = getenv("SPA3D_NT_OCC"); if (e) c->nt_occ = atoi(e);
   e = getenv("SPA3D_NT_8P"); if (e) c->nt_8p = atoi(e);
   e = getenv("SPA3D_NT_8PP"); if (e) c->nt_8pp = atoi(e);

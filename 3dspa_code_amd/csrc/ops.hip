@@ -11,6 +11,7 @@ struct OpCtx : spa3d_ctx {
     stream = (hipStream_t)stream_; ar.base = (char*)ws; ar.cap = ws_bytes;
     const char* e = getenv("SPA3D_NT_OCC"); if (e) nt_occ = atoi(e);
     e = getenv("SPA3D_NT_8P"); if (e) nt_8p = atoi(e);
+    e = getenv("SPA3D_ATTN_BWD_MODE"); if (e) attn_bwd_mode = atoi(e);
     e = getenv("SPA3D_NT_8PP"); if (e) nt_8pp = atoi(e);
     e = getenv("SPA3D_NT_COARSE"); if (e) nt_coarse = atoi(e);
     e = getenv("SPA3D_NT_STREAM"); if (e) nt_stream = atoi(e);

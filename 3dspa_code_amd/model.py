@@ -488,22 +488,18 @@ class TrackAutoEncoder(TrackAutoEncoder3D):
 
 
 PROF_CLASSES = ('gemm_nt_bf16 (tiled MFMA, Y=X.W / dX=dY.W^T)', 'gemm_tn_bf16 (tiled MFMA, dW=X^T.dY)', 'gemm_generic (strided MFMA)',
-                'attention_fused_fwd', 'attention_fused_bwd')
+                'attention_fused_fwd', 'attention_fused_bwd', 'layernorm_fwd', 'layernorm_bwd', 'attention_single_query (pruned last block)')
 
 
 def profile_summary(model, handle, peak_flops: float = 2.5e15):
-  """Reads the live HIP-event timings (spa3d_prof_*) and returns bench.py's `roofline` object for the dominant class."""
+  """Reads the live HIP-event timings (spa3d_prof_*): one row per instrumented kernel class with its launches, device ms,
+  algorithmic FLOPs and algorithmic bytes (bench.py prices each class against its own roofline)."""
   lib = _lib.load()
   rows = []
   for cls, name in enumerate(PROF_CLASSES):
     o = (C.c_double * 4)()
     _lib.check(lib.spa3d_prof_read(handle, cls, o), handle, 'spa3d_prof_read')
     rows.append({'kernel': name, 'launches': int(o[0]), 'ms': o[1], 'flops': o[2], 'bytes': o[3]})
-  dom = max(rows, key=lambda r: r['ms'])
-  if dom['launches'] == 0:
+  if not any(r['launches'] for r in rows):
     return None
-  ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-  return {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': ach, 'peak': peak_flops / 1e12, 'unit': 'TFLOP/s',
-          'frac': ach * 1e12 / peak_flops, 'traffic': None, 'launches': dom['launches'],
-          'avg_launch_ms': dom['ms'] / dom['launches'], 'flops_per_launch': dom['flops'] / dom['launches'],
-          'classes': [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]}
+  return {'classes': rows, 'peak': peak_flops}

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- train-step tracks/sec of the 3DSPA hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus 1 --steps K --warmup W [--config {1,2,3}]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One step = forward + compute_loss_3d + backward + (RCCL gradient all-reduce) + clip/AdamW over one synthetic
-batch resident in HBM.  Workload at every N: BASELINE.json configs[2] per GPU (B=64, 2048 support + 512 query,
+batch resident in HBM.  Default workload at every N: BASELINE.json configs[2] per GPU (B=64, 2048 support + 512 query,
 T=150, xyz+depth+DINOv2-768, bf16) => weak scaling; configs[3] is exactly this at N=8 (global B=512).
+--config 2: configs[1] (xyz+depth only, C=4); --config 1: configs[0]'s shape (B=2, 64+16 tracks, T=24, xyz-only, fp32) on the GPU.
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
 """
 from __future__ import annotations
@@ -14,6 +15,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -25,14 +27,28 @@ import torch
 import torch.distributed as dist
 
 # algorithmic work of the reference graph per sample at N=2048,Q=512,T=150,C=772 (SURVEY 0.4 / BASELINE.md 3):
-F_REF_FWD_PER_STEP_B64 = 598.6e12  # forward FLOPs at B=64
+F_REF_FWD_PER_STEP_B64 = {3: 598.6e12, 2: 587.0e12}  # forward FLOPs at B=64 (C=772 / C=4)
 PEAK_BF16_FLOPS = 2.5e15  # dense bf16 MFMA, MI355X_MICROARCH.md chip table
+PEAK_F32_FLOPS = 157.3e12
 PEAK_HBM = 8.0e12
 
+CONFIGS = {
+    1: dict(B=2, N=64, Q=16, T=24, dino=0, depth=0, precision='fp32', name='BASELINE configs[0] shape on the GPU: B=2, 64 support + 16 query, T=24, xyz-only, fp32'),
+    2: dict(B=64, N=2048, Q=512, T=150, dino=0, depth=1, precision='bf16', name='BASELINE configs[1] per GPU: B=64, 2048 support + 512 query, T=150, xyz+depth(1) (C=4)'),
+    3: dict(B=64, N=2048, Q=512, T=150, dino=768, depth=1, precision='bf16', name='BASELINE configs[2] per GPU: B=64, 2048 support + 512 query, T=150, xyz+depth(1)+DINOv2-768'),
+}
 
-def synth_batch(B, N, Q, T, dino_dim, depth_dim, device, seed):
+# profile class -> (bound, kernel-name prefixes in the rocprofv3 summaries under profiles/)
+CLASS_INFO = {
+    'gemm_nt_bf16': ('mfma', ('gemm_nt',)), 'gemm_tn_bf16': ('mfma', ('gemm_tn',)), 'gemm_generic': ('mfma', ('gemm_generic',)),
+    'attention_fused_fwd': ('hbm', ('attn_fwd',)), 'attention_fused_bwd': ('hbm', ('attn_bwd',)),
+    'layernorm_fwd': ('hbm', ('ln_fwd',)), 'layernorm_bwd': ('hbm', ('ln_bwd',)), 'attention_single_query': ('hbm', ('attn_q1',)),
+}
+
+
+def synth_batch(B, N, Q, T, dino_dim, depth_dim, device, seed, feat_dtype=torch.bfloat16):
   """random-walk tracks in [0,1]^3, Bernoulli(0.9) visibility, boundary_frame=T, depth=z,
-  DINO ~ N(0,1) bf16, query point = (random frame, position of the query track at that frame)."""
+  DINO ~ N(0,1), query point = (random frame, position of the query track at that frame)."""
   g = torch.Generator(device=device).manual_seed(seed)
 
   def walk(n):
@@ -53,64 +69,129 @@ def synth_batch(B, N, Q, T, dino_dim, depth_dim, device, seed):
       'query_tracks_visible': (torch.rand(B, Q, T, 1, generator=g, device=device) < 0.9).float(),
   }
   if depth_dim:
-    batch['depth_features'] = sup[..., 2:3].expand(B, N, T, depth_dim).to(torch.bfloat16).contiguous()
+    batch['depth_features'] = sup[..., 2:3].expand(B, N, T, depth_dim).to(feat_dtype).contiguous()
   if dino_dim:
-    d = torch.empty(B, N, T, dino_dim, dtype=torch.bfloat16, device=device)
+    d = torch.empty(B, N, T, dino_dim, dtype=feat_dtype, device=device)
     for b in range(B):  # 0.47 GB per sample; generated in place
-      d[b] = torch.randn(N, T, dino_dim, generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
+      d[b] = torch.randn(N, T, dino_dim, generator=g, device=device, dtype=torch.float32).to(feat_dtype)
     batch['dino_features'] = d
   return batch
 
 
-def pmc_traffic(kernel_class: str, launches_per_step: float):
-  """HBM traffic per launch of the dominant kernel class from the committed rocprofv3 --pmc passes of this same command
-  (profiles/r01_bench_b64_pmc_{fetch,write}.csv: separate passes, KiB units, FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM").
-  Returns (bytes_per_launch, source) or (None, None) when the summaries are absent or the class is unknown."""
+def pmc_tables():
+  """Per-kernel FETCH_SIZE / WRITE_SIZE totals of the committed rocprofv3 --pmc passes of this same command (separate passes, KiB
+  units; `tools/profile_round.sh`).  Newest round first."""
   import csv
-  prefix = {'gemm_nt_bf16': 'gemm_nt', 'gemm_tn_bf16': 'gemm_tn', 'attention_fused_bwd': 'attn_bwd', 'attention_fused_fwd': 'attn_fwd',
-            'gemm_generic': 'gemm_generic'}.get(kernel_class.split(' ')[0])
-  f_fetch = os.path.join(ROOT, 'profiles', 'r01_bench_b64_pmc_fetch.csv'); f_write = os.path.join(ROOT, 'profiles', 'r01_bench_b64_pmc_write.csv')
-  if prefix is None or not (os.path.exists(f_fetch) and os.path.exists(f_write)):
-    return None, None
-  def total(path, counter):
-    t, n = 0.0, 0
-    for r in csv.DictReader(open(path)):
-      if r['counter'] == counter and r['kernel'].startswith(prefix):
-        t += float(r['total']); n += int(r['dispatches'])
-    return t, n
-  fetch, n = total(f_fetch, 'FETCH_SIZE'); write, _ = total(f_write, 'WRITE_SIZE')
-  if n == 0:
-    return None, None
-  return (2.0 * fetch + write) * 1024.0 / n, 'profiles/r01_bench_b64_pmc_fetch.csv + _write.csv (rocprofv3 --pmc, bench.py --steps 1 --warmup 0)'
+  for tag in ('r02', 'r01'):
+    f_fetch = os.path.join(ROOT, 'profiles', f'{tag}_bench_b64_pmc_fetch.csv'); f_write = os.path.join(ROOT, 'profiles', f'{tag}_bench_b64_pmc_write.csv')
+    if os.path.exists(f_fetch) and os.path.exists(f_write):
+      rows = list(csv.DictReader(open(f_fetch))) + list(csv.DictReader(open(f_write)))
+      return rows, f'profiles/{tag}_bench_b64_pmc_fetch.csv + _write.csv (rocprofv3 --pmc, bench.py --steps 1)'
+  return [], None
 
 
-def cpu_baseline():
-  """The CPU restatement of the reference graph (oracle, kind "port") timed on this host: BASELINE.json configs[0]
-  (B=2, 64+16 tracks, T=24, xyz-only, fp32), one fwd+bwd step.  The reference's own JAX path cannot run here
-  (SURVEY F2/F3)."""
-  from oracle import spa3d_oracle as O
+def pmc_traffic(rows, prefixes):
+  """HBM traffic per launch of a kernel class: (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB / dispatches -- FETCH_SIZE doubled as
+  MI355X_MICROARCH.md "HBM" prescribes for wide coalesced reads on gfx950 (an upper bound for narrower access shapes)."""
+  fetch = write = 0.0
+  n = 0
+  for r in rows:
+    if not any(r['kernel'].startswith(p) for p in prefixes):
+      continue
+    if r['counter'] == 'FETCH_SIZE':
+      fetch += float(r['total']); n += int(r['dispatches'])
+    elif r['counter'] == 'WRITE_SIZE':
+      write += float(r['total'])
+  return (2.0 * fetch + write) * 1024.0 / n if n else None
+
+
+def roofline_from_profile(spa3d, model, handle, steps, peak_flops):
+  """Live HIP-event timings of every instrumented kernel class (spa3d_prof_*), each priced against ITS roofline:
+  MFMA classes against the dense MFMA peak, HBM classes against 8 TB/s, with the PMC traffic ratio where a committed pass has it."""
+  raw = spa3d.profile_summary(model, handle, peak_flops)
+  if raw is None:
+    return None
+  rows, src = pmc_tables()
+  classes = []
+  for c in raw['classes']:
+    key = c['kernel'].split(' ')[0]
+    bound, prefixes = CLASS_INFO.get(key, ('mfma', ()))
+    if c['launches'] == 0:
+      continue
+    sec = c['ms'] * 1e-3
+    alg = c['bytes'] / c['launches']
+    traffic = pmc_traffic(rows, prefixes) if prefixes else None
+    e = {'kernel': c['kernel'], 'bound': bound, 'launches': c['launches'], 'ms_per_step': round(c['ms'] / max(1, steps), 3),
+         'avg_launch_ms': round(c['ms'] / c['launches'], 4)}
+    if bound == 'mfma':
+      e.update(achieved=round(c['flops'] / sec / 1e12, 2), peak=peak_flops / 1e12, unit='TFLOP/s', frac=round(c['flops'] / sec / peak_flops, 4))
+    else:
+      e.update(achieved=round(c['bytes'] / sec / 1e9, 1), peak=PEAK_HBM / 1e9, unit='GB/s', frac=round(c['bytes'] / sec / PEAK_HBM, 4))
+    e['algorithmic_bytes_per_launch'] = round(alg)
+    e['traffic'] = round(traffic) if traffic else None
+    e['traffic_ratio'] = round(traffic / alg, 3) if traffic and alg else None
+    classes.append(e)
+  if not classes:
+    return None
+  dom = max(classes, key=lambda r: r['ms_per_step'])
+  out = {k: dom[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launches', 'avg_launch_ms',
+                             'algorithmic_bytes_per_launch', 'traffic_ratio')}
+  out['traffic_source'] = src
+  out['classes'] = classes
+  mfma_flops = sum(c['flops'] for c in raw['classes'] if CLASS_INFO.get(c['kernel'].split(' ')[0], ('mfma',))[0] == 'mfma')
+  return out, mfma_flops
+
+
+def cpu_threads():
   # the box's CPU share, not the host's core count: os.cpu_count() over-subscribes a cgroup-limited container
   try:
     cores = len(os.sched_getaffinity(0))
   except AttributeError:
     cores = os.cpu_count() or 1
-  cores = max(1, min(cores, int(os.environ.get('SPA3D_CPU_THREADS', 16))))
-  torch.set_num_threads(cores)
+  return max(1, min(cores, int(os.environ.get('SPA3D_CPU_THREADS', 16))))
+
+
+def cpu_baseline():
+  """The CPU restatement of the reference graph (oracle, kind "port") timed on this host: BASELINE.json configs[0]
+  (B=2, 64+16 tracks, T=24, xyz-only, fp32), FULL step = fwd + loss + bwd + clip + AdamW, median of 5 after 1 warm-up
+  (SURVEY 8(d)).  The reference's own JAX path cannot run here."""
+  from oracle import spa3d_oracle as O
+  torch.set_num_threads(cpu_threads())
   cfg = O.Config(num_output_frames=24, use_dino=False, use_depth=False)
-  p = O.init_params(cfg, seed=0, with_dino=False, with_depth=False)
+  p = O.tree_flatten(O.init_params(cfg, seed=0, with_dino=False, with_depth=False))
+  m_ = {k: torch.zeros_like(v) for k, v in p.items()}
+  v_ = {k: torch.zeros_like(v) for k, v in p.items()}
   b = O.synthetic_batch(2, 64, 16, 24)
-  m = O.TrackAutoEncoder3D(cfg)
+  model = O.TrackAutoEncoder3D(cfg)
   noise = torch.rand(2, 128, 96)
-  O.loss_and_grads(m, p, b, noise=noise)  # warm-up
   ts = []
-  for _ in range(2):
+  for step in range(6):
     t0 = time.perf_counter()
-    O.loss_and_grads(m, p, b, noise=noise)
+    _, _, g = O.loss_and_grads(model, O.tree_unflatten(p), b, noise=noise)
+    O.adamw_step(p, g, m_, v_, step, 1e-4)
     ts.append(time.perf_counter() - t0)
-  t = min(ts)
+  t = statistics.median(ts[1:])
   return {'value': 160.0 / t, 'unit': 'tracks/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-          'sample': f'cfg#1 B=2, 64 support+16 query, T=24, xyz-only fp32, 1 fwd+bwd step (best of 2 after 1 warm-up): {t:.2f} s/step, '
-                    f'{1.02e12 / t / 1e9:.1f} GFLOP/s of F_ref=1.02 TFLOP'}
+          'sample': f'cfg#1 B=2, 64 support+16 query, T=24, xyz-only fp32, full step fwd+loss+bwd+clip+AdamW (median of 5 after 1 warm-up): '
+                    f'{t:.2f} s/step, {1.02e12 / t / 1e9:.1f} GFLOP/s of F_ref=1.02 TFLOP'}
+
+
+def gpu_same_shape(spa3d, dev):
+  """The cfg#1 shape on the GPU (both precisions), so the GPU/CPU ratio also exists at IDENTICAL shape, not only across configs."""
+  out = {}
+  c = CONFIGS[1]
+  for precision in ('fp32', 'bf16'):
+    model = spa3d.TrackAutoEncoder3D(num_output_frames=c['T'], use_dino=False, use_depth=False, precision=precision)
+    batch = synth_batch(c['B'], c['N'], c['Q'], c['T'], 0, 0, dev, seed=7)
+    st = spa3d.TrainState(model, model.init(0, batch)['params'])
+    st.train_step(batch); torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+      t0 = time.perf_counter(); st.train_step(batch); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    t = statistics.median(ts)
+    out[precision] = {'ms_per_step': round(t * 1e3, 3), 'tracks_per_s': round(160.0 / t, 1)}
+    del st, model
+  return out
 
 
 def main():
@@ -118,10 +199,11 @@ def main():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=3)
   ap.add_argument('--warmup', type=int, default=1)
-  ap.add_argument('--batch', type=int, default=int(os.environ.get('SPA3D_BENCH_B', 64)), help='per-GPU batch (default 64)')
-  ap.add_argument('--support', type=int, default=2048)
-  ap.add_argument('--query', type=int, default=512)
-  ap.add_argument('--frames', type=int, default=150)
+  ap.add_argument('--config', type=int, default=3, choices=(1, 2, 3), help='BASELINE.json configs[N-1] (default 3 = the headline C=772 workload)')
+  ap.add_argument('--batch', type=int, default=None, help='per-GPU batch override (dev runs)')
+  ap.add_argument('--support', type=int, default=None)
+  ap.add_argument('--query', type=int, default=None)
+  ap.add_argument('--frames', type=int, default=None)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   args = ap.parse_args()
 
@@ -137,10 +219,15 @@ def main():
     dist.init_process_group('nccl', device_id=dev)
 
   import spa3d
-  B, N, Q, T = args.batch, args.support, args.query, args.frames
-  model = spa3d.TrackAutoEncoder3D(num_output_frames=T, dino_feature_dim=768, depth_feature_dim=1, precision='bf16')
-  batch = synth_batch(B, N, Q, T, 768, 1, dev, seed=1234 + rank)
-  params = model.init(0, batch)['params']  # same seed on every rank: replicas start identical
+  cfg = dict(CONFIGS[args.config])
+  B = args.batch or int(os.environ.get('SPA3D_BENCH_B', cfg['B']))
+  N, Q, T = args.support or cfg['N'], args.query or cfg['Q'], args.frames or cfg['T']
+  dino, depth, precision = cfg['dino'], cfg['depth'], cfg['precision']
+  fdt = torch.bfloat16 if precision == 'bf16' else torch.float32
+  model = spa3d.TrackAutoEncoder3D(num_output_frames=T, dino_feature_dim=max(dino, 1), depth_feature_dim=max(depth, 1), use_dino=dino > 0,
+                                   use_depth=depth > 0, precision=precision)
+  batch = synth_batch(B, N, Q, T, dino, depth, dev, seed=1234 + rank, feat_dtype=fdt)
+  params = model.init(0, batch)['params']  # TrainState broadcasts rank 0's parameters: replicas start identical whatever the seed
   state = spa3d.TrainState(model, params, learning_rate=1e-4, warmup_steps=10000, total_steps=1000000)
   lib = spa3d._lib.load()
 
@@ -152,8 +239,8 @@ def main():
   for _ in range(args.warmup):
     state.train_step(batch)
   sync()
-  prof = hasattr(lib, 'spa3d_prof_enable') and os.environ.get('SPA3D_BENCH_PROF', '1') == '1'
-  h = model._handle(768, 1)[0]
+  prof = os.environ.get('SPA3D_BENCH_PROF', '1') == '1'
+  h = model._handle(dino, depth)[0]
   if prof:
     lib.spa3d_prof_enable(h, 1)
   t0 = time.perf_counter()
@@ -161,13 +248,13 @@ def main():
     metrics = state.train_step(batch)
   sync()
   dt = time.perf_counter() - t0
-  roof = None
+  peak = PEAK_BF16_FLOPS if precision == 'bf16' else PEAK_F32_FLOPS
+  roof, mfma_flops = None, None
   if prof:
-    roof = spa3d.profile_summary(model, h)
+    r = roofline_from_profile(spa3d, model, h, args.steps, peak)
     lib.spa3d_prof_enable(h, 0)
-    if roof is not None:
-      roof['traffic'], roof['traffic_source'] = pmc_traffic(roof['kernel'], roof['launches'] / max(1, args.steps))
-      roof['algorithmic_bytes_per_launch'] = next(c['bytes'] / max(1, c['launches']) for c in roof['classes'] if c['kernel'] == roof['kernel'])
+    if r is not None:
+      roof, mfma_flops = r
   tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
   if world > 1:
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -177,20 +264,31 @@ def main():
   if rank == 0:
     tracks = world * B * (N + Q) * args.steps
     ms = dt / args.steps * 1e3
-    scale = (B / 64.0) * (N / 2048.0) * (T / 150.0)  # F_ref scales ~linearly in B; other dims only for dev runs
+    C = 3 + depth + dino
     out = {
-        'metric': 'train-step tracks/sec (B x N_tracks) at T=150, C=772', 'value': tracks / dt, 'unit': 'tracks/s',
+        'metric': f'train-step tracks/sec (B x N_tracks) at T={T}, C={C}', 'value': tracks / dt, 'unit': 'tracks/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': f'BASELINE configs[2] per GPU: B={B}, {N} support + {Q} query, T={T}, xyz+depth(1)+DINOv2-768, '
-                               'fwd+loss+bwd+clip+AdamW', 'per_gpu_batch': B, 'global_batch': B * world, 'support': N, 'query': Q,
-                   'frames': T, 'channels': 772, 'parallelism': f'dp{world}', 'chunk_samples': int(os.environ.get('SPA3D_CHUNK', 0)),
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if precision == 'bf16' else 'f32', 'data': 'synthetic',
+        'config': {'workload': cfg['name'] + ', fwd+loss+bwd+clip+AdamW' + (f' [overrides: B={B}, N={N}, Q={Q}, T={T}]' if (B, N, Q, T) != (cfg['B'], cfg['N'], cfg['Q'], cfg['T']) else ''),
+                   'baseline_config': args.config, 'per_gpu_batch': B, 'global_batch': B * world, 'support': N, 'query': Q,
+                   'frames': T, 'channels': C, 'parallelism': f'dp{world}', 'chunk_samples': int(os.environ.get('SPA3D_CHUNK', 0)),
                    'final_loss': loss},
-        'step_mfma_frac_F_ref': (3 * F_REF_FWD_PER_STEP_B64 * scale / (ms / 1e3)) / PEAK_BF16_FLOPS,
         'roofline': roof,
     }
+    if args.config in F_REF_FWD_PER_STEP_B64:
+      scale = (B / 64.0) * (N / 2048.0) * (T / 150.0)  # F_ref scales ~linearly in B; other dims only for dev runs
+      out['step_mfma_frac_F_ref'] = (3 * F_REF_FWD_PER_STEP_B64[args.config] * scale / (ms / 1e3)) / peak  # reference graph, nothing pruned
+    if mfma_flops:
+      out['step_mfma_frac_executed'] = (mfma_flops / args.steps / (ms / 1e3)) / peak  # FLOPs the MFMA kernels actually ran (pruned last blocks)
     if world == 1 and not args.no_cpu_baseline:
-      out['cpu_baseline'] = cpu_baseline()
+      cb = cpu_baseline()
+      if args.config != 1:
+        del state, batch, params
+        model._ws = None
+        torch.cuda.empty_cache()
+        cb['gpu_same_shape'] = gpu_same_shape(spa3d, dev)
+        cb['gpu_same_shape']['note'] = 'cfg#1 shape, full train step on this GPU; CPU value above is the same shape'
+      out['cpu_baseline'] = cb
     print(json.dumps(out), flush=True)
   if world > 1:
     dist.destroy_process_group()

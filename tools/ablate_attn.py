@@ -1,7 +1,21 @@
-"""Fused attention forward/backward at the track-encoder shape (16384 sequences x 8 heads, S=151)."""
-import ctypes as C, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""Diagnostic only: builds a SEPARATE library (tools/_ablate/libspa3d_ablate.so) whose attention_fused.hip is compiled with
+-DSPA3D_ABLATE (work-skipping masks; never defined for the product libspa3d_hip.so) and times the fused attention backward with parts
+removed, to see where a problem's time goes.  Outputs of an ablated run are wrong by construction; read SHARES only.
+    python tools/ablate_attn.py            (S, NSEQ from the environment as in tools/bench_attn.py)"""
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import importlib
+b = importlib.import_module('3dspa_code_amd.build')
+out = os.path.join(ROOT, 'tools', '_ablate'); os.makedirs(out, exist_ok=True)
+b.build(verbose=False)
+objs = [os.path.join(b.HERE, 'build', s.replace('.hip', '.o')) for s in b.SOURCES if s != 'attention_fused.hip']
+ao = os.path.join(out, 'attention_fused_ablate.o')
+subprocess.check_call([b._hipcc()] + b.FLAGS + ['-DSPA3D_ABLATE', '-c', os.path.join(b.CSRC, 'attention_fused.hip'), '-o', ao])
+lib_path = os.path.join(out, 'libspa3d_ablate.so')
+subprocess.check_call([b._hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib_path] + objs + [ao])
 import torch, spa3d
+spa3d._lib.LIB_PATH = lib_path
 lib = spa3d._lib.load()
 s = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 nseq, S, H, Dh = int(os.environ.get('NSEQ', 16384)), int(os.environ.get('S', 151)), 8, 96
@@ -22,6 +36,7 @@ def timeit(fn, n=5):
   for _ in range(n): fn()
   e1.record(); torch.cuda.synchronize()
   return e0.elapsed_time(e1) / n
-tf, tb = timeit(fwd), timeit(bwd)
-rb_f = nseq * H * S * Dh * 2 * 4; rb_b = nseq * H * S * Dh * 2 * 8
-print(f'S={S} nseq={nseq} BWD_MODE={os.environ.get("SPA3D_ATTN_BWD_MODE","0")} fwd {tf:.3f} ms ({rb_f/tf/1e6:.0f} GB/s)  bwd {tb:.3f} ms ({rb_b/tb/1e6:.0f} GB/s)')
+assert fwd() == 0
+for mask, what in ((0, 'full'), (1, 'staging only (no tile work)'), (2, 'tile work only (no staging)'), (4, 'no dq/dk/dv stores'), (6, 'tile work, no staging, no stores')):
+  os.environ['SPA3D_ABLATE'] = str(mask)
+  print(f'S={S} nseq={nseq} ablate={mask} [{what}]: bwd {timeit(bwd):.3f} ms', flush=True)
