@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libspa3d_hip.so')
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2  # spa3d_config::precision / op dtype (include/spa3d.h)
 
 
 class Config(C.Structure):

@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libspa3d_hip.so')
 SOURCES = ['kernels.hip', 'gemm_generic.hip', 'gemm_fast.hip', 'attention.hip', 'attention_fused.hip', 'ops.hip', 'samplers.hip', 'model.hip']
+F16_SOURCES = ['kernels.hip', 'gemm_generic.hip', 'gemm_fast.hip', 'attention.hip', 'attention_fused.hip', 'ops.hip', 'model.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function', '-Wno-inline-asm',
          '-Wno-unused-variable', '-Wno-unused-but-set-variable']
 
@@ -34,16 +35,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
   objdir = os.path.join(HERE, 'build')
   os.makedirs(objdir, exist_ok=True)
   srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+  # every source with 16-bit device code is compiled twice: bf16 (default) and, with -DSPA_F16=1, IEEE fp16 (common.hpp)
+  units = [(s, s.replace('.hip', '.o'), []) for s in srcs] + [(s, s.replace('.hip', '_f16.o'), ['-DSPA_F16=1']) for s in srcs if s in F16_SOURCES]
   jobs = []
-  for s in srcs:
+  for s, o, extra in units:
     src = os.path.join(CSRC, s)
-    obj = os.path.join(objdir, s.replace('.hip', '.o'))
+    obj = os.path.join(objdir, o)
     if force or _stale(obj, [src] + hdrs):
-      jobs.append((src, obj))
+      jobs.append((src, obj, extra))
 
   def cc(job):
-    src, obj = job
-    cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+    src, obj, extra = job
+    cmd = [hipcc] + FLAGS + extra + ['-c', src, '-o', obj]
     if verbose:
       print(' '.join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -53,9 +56,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
       print(r.stderr, file=sys.stderr)
     return obj
 
-  with ThreadPoolExecutor(max_workers=4) as ex:
+  with ThreadPoolExecutor(max_workers=6) as ex:
     list(ex.map(cc, jobs))
-  objs = [os.path.join(objdir, s.replace('.hip', '.o')) for s in srcs]
+  objs = [os.path.join(objdir, o) for _, o, _ in units]
   if force or jobs or _stale(LIB, objs):
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
     if verbose:

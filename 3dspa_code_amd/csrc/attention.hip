@@ -7,6 +7,8 @@
 
 #include "common.hpp"
 
+namespace SPA_NS {
+
 bool attn_fused_fwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ldq, int64_t ldk, int64_t ldv,
                          const float* sq, const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, bf16_t* o,
                          float* lse);
@@ -126,3 +128,4 @@ void attention_bwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq
                                  const float*, int64_t, int, int, int, int, const T*, const float*, const T*, T*, T*, T*, float*, float*, int);
 INST_ATTN(float)
 INST_ATTN(bf16_t)
+}  // namespace SPA_NS

@@ -24,6 +24,8 @@
 #include "common.hpp"
 #include <type_traits>
 
+namespace SPA_NS {
+
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
@@ -848,3 +850,4 @@ bool attn_fused_bwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const b
   SPA_LAUNCH_CHECK(c);
   return true;
 }
+}  // namespace SPA_NS

@@ -7,15 +7,45 @@
 
 #include "../../include/spa3d.h"
 
-typedef unsigned short bf16_t;  // raw bf16 bits; arithmetic is always done in f32
+// One translation unit is compiled for exactly ONE 16-bit activation type: bf16 (default) or IEEE fp16 (-DSPA_F16=1, BASELINE
+// cfg#5).  The raw 16-bit storage type is `bf16_t` (unsigned short) in both builds; what differs -- the two conversions, the MFMA
+// instruction, the packed dot product -- is defined here, and everything device-side lives in a per-type namespace so the two builds
+// of every source link into one library.  (No dual "platform" paths: both are gfx950-only code.)
+#ifndef SPA_F16
+#define SPA_F16 0
+#endif
+#if SPA_F16
+#define SPA_NS h_f16
+#else
+#define SPA_NS h_bf16
+#endif
+typedef unsigned short bf16_t;  // raw 16-bit pattern (bf16, or fp16 in the SPA_F16 build); arithmetic is always done in f32
 
+namespace SPA_NS {
+#if SPA_F16
+__device__ __forceinline__ float bf2f(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+// round-to-nearest-even; overflows to inf beyond 65504 and flushes below 6e-8 (the fp16 mode scales the loss, model.hip)
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+typedef __attribute__((ext_vector_type(8))) _Float16 mfma16x8;
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define DOT2C_F32_16 "v_dot2c_f32_f16"
+#define ONES2_16 0x3C003C00u  // (1.0, 1.0)
+#else
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 // round-to-nearest-even; a plain cast emits v_cvt_pk_bf16_f32 and keeps NaN a NaN
 // (MI355X_MICROARCH.md "Correctness boundaries")
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
-// the 16-bit activation type's MFMA operand vector and instruction (8 elements per lane, 16x16x32)
+// the 16-bit activation type's MFMA operand vector and instructions (8 elements per lane)
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma16x8;
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define DOT2C_F32_16 "v_dot2c_f32_bf16"
+#define ONES2_16 0x3F803F80u  // (1.0, 1.0)
+#endif
+// the two 16-bit halves of a packed dword as f32
+__device__ __forceinline__ float unpack_lo(unsigned u) { return bf2f((bf16_t)(u & 0xffffu)); }
+__device__ __forceinline__ float unpack_hi(unsigned u) { return bf2f((bf16_t)(u >> 16)); }
 template <typename T> __device__ __forceinline__ float ld(const T* p);
 template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf2f(*p); }
@@ -59,6 +89,8 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+}  // namespace SPA_NS
 
 // ------------------------------------------------------------------------------------------
 // host-side context
@@ -112,6 +144,7 @@ struct spa3d_ctx {
   int hip_err = 0;
   int gemm_impl = 0;  // 0 auto, 1 generic only
   int attn_impl = 0;
+  float loss_scale = 1.f;  // backward runs at loss x loss_scale (fp16 mode: 4096), parameter gradients are scaled back at the end
   int attn_bwd_mode = 0;  // fused attention backward structure: 0 auto, 1 four images + concurrent roles, 2 split-pass 4 waves (2 WG/CU), 3 split-pass 8 waves
   int nt_8p = 1;      // 8-phase kernels (256x256 / 128x384, counted vmcnt, staggered wave rows); 2 = also for small M, 0/3 = off
   int tn_8p = 1;      // 8-phase TN (dW) kernels; SPA3D_TN_8P=0 disables, =2 forces (tests)
@@ -175,6 +208,7 @@ struct GemmDesc {
   const void* zero_page = nullptr;        // >= 16 B of zeros (tiled TN kernel: rows past the end of the reduction)
 };
 
+namespace SPA_NS {
 template <typename T> void gemm_generic(spa3d_ctx* c, const GemmDesc& d);
 // tiled bf16 kernels (gemm_fast.hip).  Return false if the shape/layout is not supported.
 bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d);
@@ -201,6 +235,7 @@ template <typename T> void k_add(spa3d_ctx*, T* dst, const T* src, int64_t n);
 void k_fill(spa3d_ctx*, float* p, float v, int64_t n);
 void k_zero(spa3d_ctx*, void* p, int64_t bytes);
 void k_mul(spa3d_ctx*, float* a, const float* b, int64_t n);
+void k_scale(spa3d_ctx*, float* a, float s, int64_t n);
 template <typename T> void k_cast_from_f32(spa3d_ctx*, const float* src, T* dst, int64_t n);
 template <typename T> void k_cast_to_f32(spa3d_ctx*, const T* src, float* dst, int64_t n);
 template <typename T> void k_pack(spa3d_ctx*, const float* src, int64_t src_ld, int rows, int cols, T* dst_native, int64_t ldn, T* dst_T, int64_t ldt);
@@ -248,3 +283,5 @@ template <typename T> void k_add_rows_strided(spa3d_ctx*, T* dst, const T* src, 
 template <typename T> void k_vis_mean_pool(spa3d_ctx*, const T* tok, const float* vis, int64_t nseq, int T_, int d, T* out);
 template <typename T> void k_vis_mean_pool_bwd(spa3d_ctx*, const T* dout, const float* vis, int64_t nseq, int T_, int d, T* dtok);
 void k_keymask2d(spa3d_ctx*, const float* visible, const int32_t* boundary, int64_t nseq, int N, int T_, float* km);
+}  // namespace SPA_NS
+using namespace SPA_NS;  // one 16-bit type per translation unit

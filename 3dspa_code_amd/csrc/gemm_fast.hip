@@ -17,9 +17,11 @@
 //   wave-instruction, the full-rate atomic shape (MI355X_MICROARCH.md "Global float atomics").
 #include "common.hpp"
 
+namespace SPA_NS {
+
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef mfma16x8 bf16x8;  // 8 activation elements: the MFMA A/B operand of one lane
 typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
 
 #define GLDS16(gptr, lptr) \
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = MFMA16(bfr[j], af[i], acc[i][j]);
     }
     __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading `cur`
   }
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
       const uint4 x4 = *(const uint4*)(g.aux + ci); const unsigned* xp = (const unsigned*)&x4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float xa = __uint_as_float(xp[r] << 16), xb = __uint_as_float(xp[r] & 0xffff0000u);
+        const float xa = unpack_lo(xp[r]), xb = unpack_hi(xp[r]);
         if (g.epi == EPI_MUL_GELU_GRAD) { v[2 * r] *= gelu_tanh_grad_fast_f(xa); v[2 * r + 1] *= gelu_tanh_grad_fast_f(xb); }
         else { v[2 * r] += xa; v[2 * r + 1] += xb; }
       }
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
       uint4* cp = (uint4*)((bf16_t*)g.C + ci);
       if (g.accumulate) { const uint4 o4 = *cp; const unsigned* op = (const unsigned*)&o4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { v[2 * r] += __uint_as_float(op[r] << 16); v[2 * r + 1] += __uint_as_float(op[r] & 0xffff0000u); } }
+        for (int r = 0; r < 4; ++r) { v[2 * r] += unpack_lo(op[r]); v[2 * r + 1] += unpack_hi(op[r]); } }
       uint4 o4; unsigned* op = (unsigned*)&o4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) op[r] = (unsigned)f2bf(v[2 * r]) | ((unsigned)f2bf(v[2 * r + 1]) << 16);
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_occ_kernel(NtArgs g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = MFMA16(bfr[j], af[i], acc[i][j]);
     }
     if (t + 1 < nt) __syncthreads();
   }
@@ -330,7 +332,7 @@ __device__ __forceinline__ void nt_store8(const NtArgs& g, int64_t gm, int gn, f
     const uint4 x4 = AUXPRE ? auxpre : *(const uint4*)(g.aux + ci); const unsigned* xp = (const unsigned*)&x4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float xa = __uint_as_float(xp[r] << 16), xb = __uint_as_float(xp[r] & 0xffff0000u);
+      const float xa = unpack_lo(xp[r]), xb = unpack_hi(xp[r]);
       if (g.epi == EPI_MUL_GELU_GRAD) { v[2 * r] *= gelu_tanh_grad_fast_f(xa); v[2 * r + 1] *= gelu_tanh_grad_fast_f(xb); }
       else { v[2 * r] += xa; v[2 * r + 1] += xb; }
     }
@@ -344,7 +346,7 @@ __device__ __forceinline__ void nt_store8(const NtArgs& g, int64_t gm, int gn, f
     uint4* cp = (uint4*)((bf16_t*)g.C + ci);
     if (g.accumulate) { const uint4 o4 = *cp; const unsigned* op = (const unsigned*)&o4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { v[2 * r] += __uint_as_float(op[r] << 16); v[2 * r + 1] += __uint_as_float(op[r] & 0xffff0000u); } }
+      for (int r = 0; r < 4; ++r) { v[2 * r] += unpack_lo(op[r]); v[2 * r + 1] += unpack_hi(op[r]); } }
     uint4 o4; unsigned* op = (unsigned*)&o4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) op[r] = (unsigned)f2bf(v[2 * r]) | ((unsigned)f2bf(v[2 * r + 1]) << 16);
@@ -365,7 +367,7 @@ __device__ __forceinline__ uint4 nt_compute8_aux(const NtArgs& g, float (&v)[8],
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float xa = __uint_as_float(xp[r] << 16), xb = __uint_as_float(xp[r] & 0xffff0000u);
+    const float xa = unpack_lo(xp[r]), xb = unpack_hi(xp[r]);
     if (g.epi == EPI_MUL_GELU_GRAD) { v[2 * r] *= gelu_tanh_grad_fast_f(xa); v[2 * r + 1] *= gelu_tanh_grad_fast_f(xb); }
     else { v[2 * r] += xa; v[2 * r + 1] += xb; }
   }
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(NtArgs g) {
 #define NT8P_MFMA(AI, BJ, BQ)                                                                                                         \
   __builtin_amdgcn_s_setprio(1);                                                                                                      \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < HM; ++i) _Pragma("unroll") for (int j = 0; j < HN; ++j) \
-      acc[(AI) + i][(BJ) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BQ[j][ks], aq[i][ks], acc[(AI) + i][(BJ) + j], 0, 0, 0);       \
+      acc[(AI) + i][(BJ) + j] = MFMA16(BQ[j][ks], aq[i][ks], acc[(AI) + i][(BJ) + j]);       \
   __builtin_amdgcn_s_setprio(0);
   int aslot = 0, aslot2 = 2;  // ring slots of K-tiles t and t+2
   for (int t = 0; t < nt; ++t) {
@@ -723,7 +725,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
 #define NT8P_MFMA(AI, BJ, BQ)                                                                                                         \
   __builtin_amdgcn_s_setprio(1);                                                                                                      \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < HM; ++i) _Pragma("unroll") for (int j = 0; j < HN; ++j) \
-      acc[(AI) + i][(BJ) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BQ[j][ks], aq[i][ks], acc[(AI) + i][(BJ) + j], 0, 0, 0);       \
+      acc[(AI) + i][(BJ) + j] = MFMA16(BQ[j][ks], aq[i][ks], acc[(AI) + i][(BJ) + j]);       \
   __builtin_amdgcn_s_setprio(0);
     int aslot = 0, aslot2 = 2;
     for (int t = 0; t < nt; ++t) {
@@ -1081,7 +1083,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const uint4 bu = make_uint4(fb[set][j * 2].x, fb[set][j * 2].y, fb[set][j * 2 + 1].x, fb[set][j * 2 + 1].y);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bu), acc[i][j], 0, 0, 0);
+          acc[i][j] = MFMA32(af, __builtin_bit_cast(bf16x8, bu), acc[i][j]);
         }
       }
     };
@@ -1232,7 +1234,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs g) {
   float cs[WNT];
 #pragma unroll
   for (int j = 0; j < WNT; ++j) cs[j] = 0.f;
-  const unsigned ones2 = 0x3F803F80u;
+  const unsigned ones2 = ONES2_16;
   const int nqp = (nq + QP - 1) / QP * QP;  // padded to whole phases: the extra quarter lies past mend and stages the zero page
   const int npro = nqp < D ? nqp : D;
   for (int q = 0; q < npro; ++q) stage();
@@ -1265,17 +1267,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs g) {
         const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(fa[u][i][0].x, fa[u][i][0].y, fa[u][i][1].x, fa[u][i][1].y));
 #pragma unroll
         for (int j = 0; j < WNT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, make_uint4(fb[u][j][0].x, fb[u][j][0].y, fb[u][j][1].x, fb[u][j][1].y)), acc[i][j], 0, 0, 0);
+          acc[i][j] = MFMA32(af, __builtin_bit_cast(bf16x8, make_uint4(fb[u][j][0].x, fb[u][j][0].y, fb[u][j][1].x, fb[u][j][1].y)), acc[i][j]);
       }
     if (do_cs) {
 #pragma unroll
       for (int u = 0; u < QP; ++u)
 #pragma unroll
         for (int j = 0; j < WNT; ++j) {
-          asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[j]) : "v"(fb[u][j][0].x), "v"(ones2));
-          asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[j]) : "v"(fb[u][j][0].y), "v"(ones2));
-          asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[j]) : "v"(fb[u][j][1].x), "v"(ones2));
-          asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(cs[j]) : "v"(fb[u][j][1].y), "v"(ones2));
+          asm(DOT2C_F32_16 " %0, %1, %2" : "+v"(cs[j]) : "v"(fb[u][j][0].x), "v"(ones2));
+          asm(DOT2C_F32_16 " %0, %1, %2" : "+v"(cs[j]) : "v"(fb[u][j][0].y), "v"(ones2));
+          asm(DOT2C_F32_16 " %0, %1, %2" : "+v"(cs[j]) : "v"(fb[u][j][1].x), "v"(ones2));
+          asm(DOT2C_F32_16 " %0, %1, %2" : "+v"(cs[j]) : "v"(fb[u][j][1].y), "v"(ones2));
         }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -1386,3 +1388,4 @@ bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d) {
   SPA_LAUNCH_CHECK(c);
   return true;
 }
+}  // namespace SPA_NS

@@ -8,8 +8,10 @@
 // F32 mode; the hot bf16 shapes use gemm_fast.hip.
 #include "common.hpp"
 
+namespace SPA_NS {
+
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef mfma16x8 bf16x8;  // 8 activation elements: the MFMA A/B operand of one lane
 
 template <typename T> struct GemmCfg;
 template <> struct GemmCfg<float> { static constexpr int BK = 16, PAD = 4; };
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = MFMA16(a[i], b[j], acc[i][j]);
     }
     __syncthreads();
   }
@@ -192,3 +194,4 @@ void gemm_generic(spa3d_ctx* c, const GemmDesc& d) {
 }
 template void gemm_generic<float>(spa3d_ctx*, const GemmDesc&);
 template void gemm_generic<bf16_t>(spa3d_ctx*, const GemmDesc&);
+}  // namespace SPA_NS

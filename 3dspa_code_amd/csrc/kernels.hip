@@ -3,6 +3,8 @@
 // fp32 math, T in {float, bf16_t} storage.  References are to /root/reference files.
 #include "common.hpp"
 
+namespace SPA_NS {
+
 #define GRID1D(n, bs) dim3((unsigned)std::min<int64_t>(((n) + (bs)-1) / (bs), 1 << 20))
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -101,7 +103,7 @@ __device__ __forceinline__ void load_vec(const T* p, float (&f)[NV]) {
   if constexpr (sizeof(T) == 4) { const float4 v = *(const float4*)p; f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
   else { const uint4 v = *(const uint4*)p; const unsigned u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(u[i] << 16); f[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); } }
+    for (int i = 0; i < 4; ++i) { f[2 * i] = unpack_lo(u[i]); f[2 * i + 1] = unpack_hi(u[i]); } }
 }
 template <typename T, int NV>
 __device__ __forceinline__ void store_vec(T* p, const float (&f)[NV]) {
@@ -963,6 +965,13 @@ void k_mul(spa3d_ctx* c, float* a, const float* b, int64_t n) {
   if (c->dry || n == 0) return;
   mul_kernel<<<GRID1D(n, 256), 256, 0, c->stream>>>(a, b, n); SPA_LAUNCH_CHECK(c);
 }
+__global__ void scale_kernel(float* __restrict__ a, float s, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a[i] *= s;
+}
+void k_scale(spa3d_ctx* c, float* a, float s, int64_t n) {
+  if (c->dry || n == 0) return;
+  scale_kernel<<<GRID1D(n, 256), 256, 0, c->stream>>>(a, s, n); SPA_LAUNCH_CHECK(c);
+}
 
 // ---------------------------------------------------------------------------------------------
 // D4-D6: readout sequence assembly without materialising tile/eye (track_autoencoder_3d.py:235-246,276-284)
@@ -1662,3 +1671,4 @@ template void k_vis_mean_pool<float>(spa3d_ctx*, const float*, const float*, int
 template void k_vis_mean_pool<bf16_t>(spa3d_ctx*, const bf16_t*, const float*, int64_t, int, int, bf16_t*);
 template void k_vis_mean_pool_bwd<float>(spa3d_ctx*, const float*, const float*, int64_t, int, int, float*);
 template void k_vis_mean_pool_bwd<bf16_t>(spa3d_ctx*, const bf16_t*, const float*, int64_t, int, int, bf16_t*);
+}  // namespace SPA_NS

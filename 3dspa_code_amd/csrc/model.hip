@@ -14,6 +14,14 @@
 #include "common.hpp"
 #include <cstdio>
 
+enum { MODE_FORWARD = 0, MODE_TRAIN = 1, MODE_ENCODE = 2, MODE_DECODE = 3 };
+
+struct RunArgs {
+  int mode; const float* P; const spa3d_batch* b; float denom; float* G; int accumulate; float* loss3; spa3d_outputs* out;
+  const float* latents_in; float* latents_out; int chunk;  // chunk: fixed Bc (>0) or 0 = as large as fits
+};
+
+namespace SPA_NS {
 template <typename T>
 void attention_fwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq,
                    const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, T* o, float* lse, int impl);
@@ -23,72 +31,6 @@ void attention_bwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq
                    T* dq, T* dk, T* dv, float* dsq, float* dsk, int impl);
 
 static const float L1_WEIGHT = 5000.0f, BCE_WEIGHT = 1e-8f;  // train.py:96
-
-// ---------------------------------------------------------------------------------------------
-// parameter tree (SURVEY 0.3): canonical leaf order = sorted Flax paths grouped per module
-// ---------------------------------------------------------------------------------------------
-static void add_leaf(spa3d_ctx* c, const std::string& name, std::initializer_list<int64_t> shape) {
-  Leaf l; l.name = name; l.ndim = (int)shape.size(); int i = 0;
-  for (auto s : shape) l.shape[i++] = s;
-  l.offset = c->nparams;
-  c->nparams += (l.numel() + 63) / 64 * 64;  // 256-B aligned leaves
-  c->leaves.push_back(l);
-}
-static void add_attn(spa3d_ctx* c, const std::string& p, int dq, int dkv) {
-  const int H = c->cfg.num_heads, Dh = c->cfg.qkv_size / H;
-  add_leaf(c, p + "/dense_query/kernel", {dq, H, Dh});
-  add_leaf(c, p + "/dense_key/kernel", {dkv, H, Dh});
-  add_leaf(c, p + "/dense_value/kernel", {dkv, H, Dh});
-  add_leaf(c, p + "/norm_query/scale", {Dh});
-  add_leaf(c, p + "/norm_key/scale", {Dh});
-  add_leaf(c, p + "/dense_out/kernel", {H, Dh, dq});
-  add_leaf(c, p + "/dense_out/bias", {dq});
-}
-static void add_xf(spa3d_ctx* c, const std::string& p, int d, int mlp, int L, int kv) {
-  for (int i = 0; i < L; ++i) {
-    std::string b = p + "/layer_" + std::to_string(i);
-    add_leaf(c, b + "/norm_q/scale", {d});
-    add_attn(c, b + "/self_att", d, d);
-    if (kv) add_attn(c, b + "/cross_att", d, kv);
-    add_leaf(c, b + "/norm_attn/scale", {d});
-    add_leaf(c, b + "/MLP_in/kernel", {d, mlp});
-    add_leaf(c, b + "/MLP_in/bias", {mlp});
-    add_leaf(c, b + "/MLP_out/kernel", {mlp, d});
-    add_leaf(c, b + "/MLP_out/bias", {d});
-  }
-  add_leaf(c, p + "/norm_encoder/scale", {d});
-}
-static void build_leaves(spa3d_ctx* c) {
-  const spa3d_config& g = c->cfg;
-  const int d = g.track_token_dim, dl = g.encoder_latent_dim, dd = g.decoder_num_channels, nf = g.num_frequencies;
-  const int NC = g.model_kind == 1 ? 2 : 3;
-  add_leaf(c, "initializer/state_init", {g.num_latent_tokens, dl});
-  // TRAJAN declares input_readout_token in setup() but never calls it (track_autoencoder.py:147), so Flax creates no parameter
-  if (g.model_kind == 0) add_leaf(c, "input_readout_token/state_init", {1, d});
-  add_leaf(c, "track_token_projection/kernel", {(NC + 1) * 2 * nf, d});
-  add_leaf(c, "track_token_projection/bias", {d});
-  if (g.dino_feature_dim > 0) {
-    add_leaf(c, "dino_projection/kernel", {g.dino_feature_dim, d});  // repair R4
-    add_leaf(c, "dino_projection/bias", {d});
-  }
-  if (g.depth_feature_dim > 0) {
-    add_leaf(c, "depth_projection/kernel", {g.depth_feature_dim, d});  // repair R5
-    add_leaf(c, "depth_projection/bias", {d});
-  }
-  add_xf(c, "input_track_transformer", d, g.enc_mlp, g.enc_layers, 0);
-  add_xf(c, "tracks_to_latents", dl, g.t2l_mlp, g.t2l_layers, d);
-  add_leaf(c, "compressor/kernel", {dl, g.latent_token_dim});
-  add_leaf(c, "compressor/bias", {g.latent_token_dim});
-  add_leaf(c, "decompressor/kernel", {g.latent_token_dim, dd - 128});
-  add_leaf(c, "decompressor/bias", {dd - 128});
-  add_xf(c, "decompress_attn", dd - 128, g.dec_mlp, g.dec_layers, 0);
-  add_xf(c, "track_readout_attn", dd, g.ro_mlp, g.ro_layers, 0);
-  const int qin = (NC * 2 * nf + 1) * 2 * nf;
-  add_leaf(c, "query_encoder/kernel", {qin, dd});
-  add_leaf(c, "query_encoder/bias", {dd});
-  add_leaf(c, "track_predictor/kernel", {dd, 4 * g.num_output_frames});
-  add_leaf(c, "track_predictor/bias", {4 * g.num_output_frames});
-}
 
 // ---------------------------------------------------------------------------------------------
 // weights as the kernels want them
@@ -526,7 +468,7 @@ template <typename T> struct Net {
       const int64_t mk = c->ar.mark();
       T* dhead = alloc<T>(nq * 4 * To);
       k_loss_bwd<T>(c, k.head, nq, To, b->query_tracks + b0 * k.Q * To * NC, b->query_tracks_visible + b0 * k.Q * To, denom_dev,
-                    L1_WEIGHT, BCE_WEIGHT, dhead, NC);
+                    L1_WEIGHT * c->loss_scale, BCE_WEIGHT * c->loss_scale, dhead, NC);  // loss_scale: 1 except in fp16 mode
       lin_bwd_w(pred, k.q0n, dhead, nq);
       T* dq0n = alloc<T>(nq * dd);
       lin_bwd_x(pred, dhead, dq0n, nq);
@@ -599,15 +541,8 @@ template <typename T> struct Net {
 // ---------------------------------------------------------------------------------------------
 // drivers
 // ---------------------------------------------------------------------------------------------
-enum { MODE_FORWARD = 0, MODE_TRAIN = 1, MODE_ENCODE = 2, MODE_DECODE = 3 };
-
-struct RunArgs {
-  int mode; const float* P; const spa3d_batch* b; float denom; float* G; int accumulate; float* loss3; spa3d_outputs* out;
-  const float* latents_in; float* latents_out; int chunk;  // chunk: fixed Bc (>0) or 0 = as large as fits
-};
-
 template <typename T>
-static void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
+void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
   const spa3d_config& g = c->cfg; const spa3d_batch* b = a.b;
   const int L = g.num_latent_tokens, Ld = g.latent_token_dim, To = g.num_output_frames;
   const bool train = a.mode == MODE_TRAIN;
@@ -653,11 +588,90 @@ static void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
     }
     c->ar.release(mk);
   }
+  if (train && c->loss_scale != 1.f) k_scale(c, a.G, 1.f / c->loss_scale, c->nparams);  // fp32 gradient buffer back to true scale
   if (train && a.loss3) k_loss_finalize(c, sums, denom_dev, L1_WEIGHT, BCE_WEIGHT, a.loss3);
 }
 
+// entry points of this build's 16-bit type (and of the fp32 parity path, which lives in the bf16 build only)
+void run_body16(spa3d_ctx* c, const RunArgs& a, int Bc) { run_body<bf16_t>(c, a, Bc); }
+#if !SPA_F16
+void run_body32(spa3d_ctx* c, const RunArgs& a, int Bc) { run_body<float>(c, a, Bc); }
+#endif
+}  // namespace SPA_NS
+
+#if !SPA_F16  // everything below exists once: host-side tree / sizing / C-ABI, dispatching on spa3d_config::precision
+namespace h_f16 { void run_body16(spa3d_ctx* c, const RunArgs& a, int Bc); }
+
+// ---------------------------------------------------------------------------------------------
+// parameter tree (SURVEY 0.3): canonical leaf order = sorted Flax paths grouped per module
+// ---------------------------------------------------------------------------------------------
+static void add_leaf(spa3d_ctx* c, const std::string& name, std::initializer_list<int64_t> shape) {
+  Leaf l; l.name = name; l.ndim = (int)shape.size(); int i = 0;
+  for (auto s : shape) l.shape[i++] = s;
+  l.offset = c->nparams;
+  c->nparams += (l.numel() + 63) / 64 * 64;  // 256-B aligned leaves
+  c->leaves.push_back(l);
+}
+static void add_attn(spa3d_ctx* c, const std::string& p, int dq, int dkv) {
+  const int H = c->cfg.num_heads, Dh = c->cfg.qkv_size / H;
+  add_leaf(c, p + "/dense_query/kernel", {dq, H, Dh});
+  add_leaf(c, p + "/dense_key/kernel", {dkv, H, Dh});
+  add_leaf(c, p + "/dense_value/kernel", {dkv, H, Dh});
+  add_leaf(c, p + "/norm_query/scale", {Dh});
+  add_leaf(c, p + "/norm_key/scale", {Dh});
+  add_leaf(c, p + "/dense_out/kernel", {H, Dh, dq});
+  add_leaf(c, p + "/dense_out/bias", {dq});
+}
+static void add_xf(spa3d_ctx* c, const std::string& p, int d, int mlp, int L, int kv) {
+  for (int i = 0; i < L; ++i) {
+    std::string b = p + "/layer_" + std::to_string(i);
+    add_leaf(c, b + "/norm_q/scale", {d});
+    add_attn(c, b + "/self_att", d, d);
+    if (kv) add_attn(c, b + "/cross_att", d, kv);
+    add_leaf(c, b + "/norm_attn/scale", {d});
+    add_leaf(c, b + "/MLP_in/kernel", {d, mlp});
+    add_leaf(c, b + "/MLP_in/bias", {mlp});
+    add_leaf(c, b + "/MLP_out/kernel", {mlp, d});
+    add_leaf(c, b + "/MLP_out/bias", {d});
+  }
+  add_leaf(c, p + "/norm_encoder/scale", {d});
+}
+static void build_leaves(spa3d_ctx* c) {
+  const spa3d_config& g = c->cfg;
+  const int d = g.track_token_dim, dl = g.encoder_latent_dim, dd = g.decoder_num_channels, nf = g.num_frequencies;
+  const int NC = g.model_kind == 1 ? 2 : 3;
+  add_leaf(c, "initializer/state_init", {g.num_latent_tokens, dl});
+  // TRAJAN declares input_readout_token in setup() but never calls it (track_autoencoder.py:147), so Flax creates no parameter
+  if (g.model_kind == 0) add_leaf(c, "input_readout_token/state_init", {1, d});
+  add_leaf(c, "track_token_projection/kernel", {(NC + 1) * 2 * nf, d});
+  add_leaf(c, "track_token_projection/bias", {d});
+  if (g.dino_feature_dim > 0) {
+    add_leaf(c, "dino_projection/kernel", {g.dino_feature_dim, d});  // repair R4
+    add_leaf(c, "dino_projection/bias", {d});
+  }
+  if (g.depth_feature_dim > 0) {
+    add_leaf(c, "depth_projection/kernel", {g.depth_feature_dim, d});  // repair R5
+    add_leaf(c, "depth_projection/bias", {d});
+  }
+  add_xf(c, "input_track_transformer", d, g.enc_mlp, g.enc_layers, 0);
+  add_xf(c, "tracks_to_latents", dl, g.t2l_mlp, g.t2l_layers, d);
+  add_leaf(c, "compressor/kernel", {dl, g.latent_token_dim});
+  add_leaf(c, "compressor/bias", {g.latent_token_dim});
+  add_leaf(c, "decompressor/kernel", {g.latent_token_dim, dd - 128});
+  add_leaf(c, "decompressor/bias", {dd - 128});
+  add_xf(c, "decompress_attn", dd - 128, g.dec_mlp, g.dec_layers, 0);
+  add_xf(c, "track_readout_attn", dd, g.ro_mlp, g.ro_layers, 0);
+  const int qin = (NC * 2 * nf + 1) * 2 * nf;
+  add_leaf(c, "query_encoder/kernel", {qin, dd});
+  add_leaf(c, "query_encoder/bias", {dd});
+  add_leaf(c, "track_predictor/kernel", {dd, 4 * g.num_output_frames});
+  add_leaf(c, "track_predictor/bias", {4 * g.num_output_frames});
+}
+
 static void run_dispatch(spa3d_ctx* c, const RunArgs& a, int Bc) {
-  if (c->cfg.precision == SPA3D_F32) run_body<float>(c, a, Bc); else run_body<bf16_t>(c, a, Bc);
+  if (c->cfg.precision == SPA3D_F32) h_bf16::run_body32(c, a, Bc);
+  else if (c->cfg.precision == SPA3D_F16) h_f16::run_body16(c, a, Bc);
+  else h_bf16::run_body16(c, a, Bc);
 }
 
 static int64_t dry_need(spa3d_ctx* c, const RunArgs& a, int Bc) {
@@ -714,7 +728,7 @@ int spa3d_create(const spa3d_config* cfg, spa3d_handle* out) {
   if (!cfg || !out) return SPA3D_ERR_ARG;
   if (cfg->num_heads <= 0 || cfg->qkv_size % cfg->num_heads) return SPA3D_ERR_ARG;  // attention.py:147-150
   if (cfg->qkv_size / cfg->num_heads > 128 || cfg->num_frequencies > 64 || cfg->num_frequencies <= 0) return SPA3D_ERR_ARG;
-  if (cfg->precision != SPA3D_F32 && cfg->precision != SPA3D_BF16) return SPA3D_ERR_ARG;
+  if (cfg->precision != SPA3D_F32 && cfg->precision != SPA3D_BF16 && cfg->precision != SPA3D_F16) return SPA3D_ERR_ARG;
   if (cfg->model_kind != 0 && cfg->model_kind != 1) return SPA3D_ERR_ARG;
   if (cfg->model_kind == 1 && (cfg->dino_feature_dim != 0 || cfg->depth_feature_dim != 0)) return SPA3D_ERR_ARG;
   if (cfg->track_token_dim > 2048 || cfg->decoder_num_channels > 2048 || cfg->encoder_latent_dim > 2048) return SPA3D_ERR_ARG;
@@ -722,7 +736,11 @@ int spa3d_create(const spa3d_config* cfg, spa3d_handle* out) {
   if (!c) return SPA3D_ERR_ARG;
   c->cfg = *cfg;
   build_leaves(c);
+  // fp16 gradients: activations' gradients of this loss sit at 1e-5..1e-7, below fp16's normal range (6.1e-5): the 16-bit backward runs
+  // at loss x 4096 and the fp32 parameter gradients are scaled back once at the end (static scale; exact for powers of two)
+  if (cfg->precision == SPA3D_F16) c->loss_scale = 4096.f;
   const char* e = getenv("SPA3D_GEMM_IMPL"); if (e) c->gemm_impl = atoi(e);
+  e = getenv("SPA3D_LOSS_SCALE"); if (e && cfg->precision == SPA3D_F16) c->loss_scale = (float)atof(e);
   e = getenv("SPA3D_ATTN_IMPL"); if (e) c->attn_impl = atoi(e);
   e = getenv("SPA3D_ATTN_BWD_MODE"); if (e) c->attn_bwd_mode = atoi(e);
   e = getenv("SPA3D_NT_OCC"); if (e) c->nt_occ = atoi(e);
@@ -778,6 +796,7 @@ int spa3d_forward(spa3d_handle h, const float* params, const spa3d_batch* b, spa
 int spa3d_loss_and_grads(spa3d_handle h, const float* params, const spa3d_batch* b, float denom, float* grads, int32_t accumulate,
                          float* loss3, spa3d_outputs* out, void* ws, int64_t ws_bytes, void* stream) {
   if (!h || !params || !grads) return SPA3D_ERR_ARG;
+  if (accumulate && h->loss_scale != 1.f) { h->err = "accumulate=1 is not supported with a loss scale (fp16 mode)"; return SPA3D_ERR_ARG; }
   RunArgs a{}; a.mode = MODE_TRAIN; a.P = params; a.b = b; a.denom = denom; a.G = grads; a.accumulate = accumulate; a.loss3 = loss3; a.out = out;
   const char* e = getenv("SPA3D_CHUNK"); if (e) a.chunk = atoi(e);
   return run(h, a, ws, ws_bytes, stream);
@@ -845,3 +864,4 @@ int spa3d_uniform_noise(float* out, int64_t n, uint32_t key0, uint32_t key1, voi
 }
 
 }  // extern "C"
+#endif  // !SPA_F16

@@ -5,6 +5,7 @@
 
 #include "common.hpp"
 
+namespace SPA_NS {
 namespace {
 struct OpCtx : spa3d_ctx {
   OpCtx(void* stream_, void* ws, int64_t ws_bytes) {
@@ -75,10 +76,46 @@ template <typename T>
 void attention_bwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq,
                    const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, const T* o, const float* lse, const T* d_o,
                    T* dq, T* dk, T* dv, float* dsq, float* dsk, int impl);
+}  // namespace SPA_NS
+
+// The entry points below are compiled twice: as declared in include/spa3d.h (this build's 16-bit type is bf16) and, with
+// -DSPA_F16=1, under a hidden `_f16` suffix with fp16 as the 16-bit type; the public functions forward dtype == SPA3D_F16 there.
+extern "C" {
+#pragma GCC visibility push(hidden)
+int spa3d_op_sin_embed_f16(const float* x, int64_t rows, int32_t C, int32_t nf, void* out, int32_t dtype, void* stream);
+int spa3d_op_linear_f16(const void* A, const void* B, const float* bias, const void* residual, void* C, int64_t M, int32_t N, int32_t K,
+                        int32_t act, int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream);
+int spa3d_op_linear_bwd_f16(const void* A, const void* B, const void* dC, void* dA, float* dB, float* dbias, int64_t M, int32_t N, int32_t K,
+                            int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream);
+int spa3d_op_layernorm_f16(const void* x, const float* scale, void* y, float* stats, int64_t rows, int32_t d, int32_t dtype, void* stream);
+int spa3d_op_layernorm_bwd_f16(const void* x, const float* scale, const float* stats, const void* dy, void* dx, float* dscale, int64_t rows,
+                               int32_t d, int32_t dtype, void* stream);
+int spa3d_op_attention_f16(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* scale_q,
+                           const float* scale_k, const float* keymask, int64_t nseq, int32_t Sq, int32_t Sk, int32_t H, int32_t Dh, void* o,
+                           float* lse, int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream);
+int spa3d_op_attention_bwd_f16(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* scale_q,
+                               const float* scale_k, const float* keymask, int64_t nseq, int32_t Sq, int32_t Sk, int32_t H, int32_t Dh,
+                               const void* o, const float* lse, const void* d_o, void* dq, void* dk, void* dv, float* dscale_q,
+                               float* dscale_k, int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream);
+#pragma GCC visibility pop
+}
+#if SPA_F16
+#define spa3d_op_sin_embed spa3d_op_sin_embed_f16
+#define spa3d_op_linear spa3d_op_linear_f16
+#define spa3d_op_linear_bwd spa3d_op_linear_bwd_f16
+#define spa3d_op_layernorm spa3d_op_layernorm_f16
+#define spa3d_op_layernorm_bwd spa3d_op_layernorm_bwd_f16
+#define spa3d_op_attention spa3d_op_attention_f16
+#define spa3d_op_attention_bwd spa3d_op_attention_bwd_f16
+#define FWD16(call)
+#else
+#define FWD16(call) if (dtype == SPA3D_F16) return call;
+#endif
 
 extern "C" {
 
 int spa3d_op_sin_embed(const float* x, int64_t rows, int32_t C, int32_t nf, void* out, int32_t dtype, void* stream) {
+  FWD16(spa3d_op_sin_embed_f16(x, rows, C, nf, out, dtype, stream))
   if (!x || !out || nf <= 0 || nf > 64) return SPA3D_ERR_ARG;
   OpCtx c(stream, nullptr, 0);
   if (dtype == SPA3D_F32) k_sin_embed<float>(&c, x, rows, C, nf, 1.0f, (float*)out);
@@ -88,6 +125,7 @@ int spa3d_op_sin_embed(const float* x, int64_t rows, int32_t C, int32_t nf, void
 
 int spa3d_op_linear(const void* A, const void* B, const float* bias, const void* residual, void* C, int64_t M, int32_t N, int32_t K,
                     int32_t act, int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream) {
+  FWD16(spa3d_op_linear_f16(A, B, bias, residual, C, M, N, K, act, dtype, impl, ws, ws_bytes, stream))
   if (!A || !B || !C) return SPA3D_ERR_ARG;
   OpCtx c(stream, ws, ws_bytes);
   if (dtype == SPA3D_F32) return op_linear<float>(c, (const float*)A, (const float*)B, bias, (const float*)residual, (float*)C, M, N, K, act, impl);
@@ -95,6 +133,7 @@ int spa3d_op_linear(const void* A, const void* B, const float* bias, const void*
 }
 int spa3d_op_linear_bwd(const void* A, const void* B, const void* dC, void* dA, float* dB, float* dbias, int64_t M, int32_t N, int32_t K,
                         int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream) {
+  FWD16(spa3d_op_linear_bwd_f16(A, B, dC, dA, dB, dbias, M, N, K, dtype, impl, ws, ws_bytes, stream))
   if (!A || !B || !dC) return SPA3D_ERR_ARG;
   OpCtx c(stream, ws, ws_bytes);
   if (dtype == SPA3D_F32) return op_linear_bwd<float>(c, (const float*)A, (const float*)B, (const float*)dC, (float*)dA, dB, dbias, M, N, K, impl);
@@ -102,6 +141,7 @@ int spa3d_op_linear_bwd(const void* A, const void* B, const void* dC, void* dA, 
 }
 
 int spa3d_op_layernorm(const void* x, const float* scale, void* y, float* stats, int64_t rows, int32_t d, int32_t dtype, void* stream) {
+  FWD16(spa3d_op_layernorm_f16(x, scale, y, stats, rows, d, dtype, stream))
   if (!x || !scale || !y || d <= 0 || d > 2048) return SPA3D_ERR_ARG;
   OpCtx c(stream, nullptr, 0);
   if (dtype == SPA3D_F32) k_layernorm<float>(&c, (const float*)x, scale, (float*)y, stats, rows, d);
@@ -110,6 +150,7 @@ int spa3d_op_layernorm(const void* x, const float* scale, void* y, float* stats,
 }
 int spa3d_op_layernorm_bwd(const void* x, const float* scale, const float* stats, const void* dy, void* dx, float* dscale, int64_t rows,
                            int32_t d, int32_t dtype, void* stream) {
+  FWD16(spa3d_op_layernorm_bwd_f16(x, scale, stats, dy, dx, dscale, rows, d, dtype, stream))
   if (!x || !scale || !stats || !dy || !dx || !dscale || d <= 0 || d > 2048) return SPA3D_ERR_ARG;
   OpCtx c(stream, nullptr, 0);
   if (dtype == SPA3D_F32) k_layernorm_bwd<float>(&c, (const float*)x, scale, stats, (const float*)dy, (float*)dx, dscale, rows, d, nullptr);
@@ -120,6 +161,7 @@ int spa3d_op_layernorm_bwd(const void* x, const float* scale, const float* stats
 int spa3d_op_attention(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* scale_q,
                        const float* scale_k, const float* keymask, int64_t nseq, int32_t Sq, int32_t Sk, int32_t H, int32_t Dh, void* o,
                        float* lse, int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream) {
+  FWD16(spa3d_op_attention_f16(q, k, v, ldq, ldk, ldv, scale_q, scale_k, keymask, nseq, Sq, Sk, H, Dh, o, lse, dtype, impl, ws, ws_bytes, stream))
   if (!q || !k || !v || !o || !scale_q || !scale_k || Dh > 128) return SPA3D_ERR_ARG;
   OpCtx c(stream, ws, ws_bytes);
   if (dtype == SPA3D_F32)
@@ -135,6 +177,8 @@ int spa3d_op_attention_bwd(const void* q, const void* k, const void* v, int64_t 
                            const void* o, const float* lse, const void* d_o, void* dq, void* dk, void* dv, float* dscale_q,
                            float* dscale_k, int32_t dtype, int32_t impl,
                            void* ws, int64_t ws_bytes, void* stream) {
+  FWD16(spa3d_op_attention_bwd_f16(q, k, v, ldq, ldk, ldv, scale_q, scale_k, keymask, nseq, Sq, Sk, H, Dh, o, lse, d_o, dq, dk, dv, dscale_q,
+                                   dscale_k, dtype, impl, ws, ws_bytes, stream))
   if (!q || !k || !v || !d_o || !dq || !dk || !dv || !dscale_q || !dscale_k || Dh > 128) return SPA3D_ERR_ARG;
   OpCtx c(stream, ws, ws_bytes);
   if (dtype == SPA3D_F32)

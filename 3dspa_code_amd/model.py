@@ -84,6 +84,10 @@ def _require_cuda(t: torch.Tensor, name: str):
     raise _lib.Spa3dError(f'{name} must live on the GPU: the 3DSPA hot path is HIP-only (no CPU fallback)')
 
 
+# precision name -> (spa3d_config::precision, dtype of the DINO / depth feature planes handed to the library)
+_PRECISIONS = {'fp32': (_lib.F32, torch.float32), 'bf16': (_lib.BF16, torch.bfloat16), 'fp16': (_lib.F16, torch.float16)}
+
+
 # ------------------------------------------------------------------------------------------------
 # the model
 # ------------------------------------------------------------------------------------------------
@@ -96,8 +100,8 @@ class TrackAutoEncoder3D:
                dino_feature_dim: int = 768, depth_feature_dim: int = 256, use_dino: bool = True, use_depth: bool = True,
                decoder_scan_chunk_size: Optional[int] = None, precision: str = 'bf16',
                workspace_fraction: float = 0.80):
-    if precision not in ('bf16', 'fp32'):
-      raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+    if precision not in _PRECISIONS:
+      raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}, got {precision!r}")
     self.num_output_frames = num_output_frames
     self.num_latent_tokens = num_latent_tokens
     self.latent_token_dim = latent_token_dim
@@ -130,7 +134,7 @@ class TrackAutoEncoder3D:
   # -------------------------------------------------------------------------------- handles / layout
   @property
   def act_dtype(self):
-    return torch.bfloat16 if self.precision == 'bf16' else torch.float32
+    return _PRECISIONS[self.precision][1]
 
   def _handle(self, dino_dim: int, depth_dim: int):
     key = (dino_dim, depth_dim)
@@ -140,7 +144,7 @@ class TrackAutoEncoder3D:
                         self.track_scale_factor, self.time_scale_factor, self.track_token_dim, self.encoder_latent_dim,
                         self.decoder_num_channels, dino_dim, depth_dim, self.num_heads, self.qkv_size, self.enc_mlp,
                         self.enc_layers, self.t2l_mlp, self.t2l_layers, self.dec_mlp, self.dec_layers, self.ro_mlp,
-                        self.ro_layers, _lib.BF16 if self.precision == 'bf16' else _lib.F32, self._kind)
+                        self.ro_layers, _PRECISIONS[self.precision][0], self._kind)
       h = C.c_void_p()
       _lib.check(lib.spa3d_create(C.byref(cfg), C.byref(h)), what='spa3d_create')
       leaves = []

@@ -41,6 +41,8 @@ extern "C" {
 
 #define SPA3D_F32 0  /* exact-fp32 path: v_mfma_f32_16x16x4_f32, fp32 activations (parity runs) */
 #define SPA3D_BF16 1 /* bf16 activations + bf16 MFMA, fp32 accumulate, fp32 master params/grads  */
+#define SPA3D_F16 2  /* IEEE fp16 activations + fp16 MFMA (same rate), fp32 accumulate / master params/grads; the 16-bit backward
+                        runs at loss x 4096 (static loss scale), BASELINE.json configs[4] */
 
 typedef struct spa3d_ctx* spa3d_handle;
 
@@ -64,7 +66,7 @@ typedef struct {
   int32_t t2l_mlp, t2l_layers; /* 2048, 4 */
   int32_t dec_mlp, dec_layers; /* 2048, 4 */
   int32_t ro_mlp, ro_layers;   /* 1536, 4 */
-  int32_t precision;           /* SPA3D_F32 | SPA3D_BF16 */
+  int32_t precision;           /* SPA3D_F32 | SPA3D_BF16 | SPA3D_F16 */
   int32_t model_kind;          /* 0 = TrackAutoEncoder3D (track_autoencoder_3d.py:43-357);
                                   1 = the 2-D TRAJAN twin TrackAutoEncoder (track_autoencoder.py:117-390): 2 coordinates, no readout
                                       token, visible-mean pooling, certainty head; dino/depth dims must be 0.  Tensors then carry 2

@@ -14,6 +14,7 @@ checked first, so a generator drift shows up as "inputs differ", not as a parity
 Cases (BASELINE.json configs[1] and configs[2] channel sets):
   c772 : xyz + depth(1) + DINOv2-768, B=2, N=6, Q=4, boundary_frame = (150, 97)
   c4   : xyz + depth(1) only (depth-only parametrisation, cfg#2), same sizes
+  c772_t300 : T = T_out = 300, B=1, N=4, Q=8 (BASELINE configs[4] sequence length; see the case table)
   c772_tiles : B=2, N=64, Q=64 -> M = 19 328 track-token rows and 16 512 readout rows, i.e. above the 16 384-row
          threshold at which the default dispatch takes the 8-phase / persistent MFMA kernels the benchmark runs on.
 bf16 inputs: DINO / depth features are rounded to bf16 before the oracle sees them (the product's bf16 mode stores
@@ -32,11 +33,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from oracle import spa3d_oracle as O  # noqa: E402
 
-T = 150
 CASES = {
     'c772': dict(B=2, N=6, Q=4, dino=768, depth=1, boundary=(150, 97), pseed=5, bseed=77),
     'c4': dict(B=2, N=6, Q=4, dino=0, depth=1, boundary=(150, 97), pseed=6, bseed=78),
     'c772_tiles': dict(B=2, N=64, Q=64, dino=768, depth=1, boundary=(150, 120), pseed=5, bseed=79),
+    # BASELINE configs[4] sequence length: T = T_out = 300 (S = 301).  Query frames are set by hand so that floor(t / 150) takes
+    # both values (track_autoencoder_3d.py:268-269) and the 128-wide window lat[:, 5t : 5t+128] runs partly (t = 205..230) and
+    # wholly (t >= 231) off the end of the 1152 latent channels (:239-245).
+    'c772_t300': dict(B=1, N=4, Q=8, T=300, dino=768, depth=1, boundary=(260,), pseed=8, bseed=80, qframes=(0, 149, 150, 204, 205, 230, 231, 299)),
 }
 KEEP_GRADS = ('input_readout_token/state_init', 'depth_projection/kernel', 'track_token_projection/bias',
               'input_track_transformer/layer_0/norm_q/scale', 'input_track_transformer/layer_2/self_att/norm_key/scale',
@@ -48,12 +52,17 @@ KEEP_GRADS = ('input_readout_token/state_init', 'depth_projection/kernel', 'trac
 def make_inputs(case):
   """(cfg, params fp32, batch fp32 with bf16-representable features, noise) of one case; shared with the tests."""
   c = CASES[case]
+  T = c.get('T', 150)
   cfg = O.Config(num_output_frames=T, use_dino=c['dino'] > 0, use_depth=c['depth'] > 0, dino_feature_dim=max(c['dino'], 1),
                  depth_feature_dim=max(c['depth'], 1))
   p = O.init_params(cfg, seed=c['pseed'], dtype=torch.float32, with_dino=c['dino'] > 0, with_depth=c['depth'] > 0,
                     depth_dim=c['depth'], perturb=0.1)
   batch = O.synthetic_batch(c['B'], c['N'], c['Q'], T, seed=c['bseed'], dino_dim=c['dino'], depth_dim=c['depth'])
   batch['boundary_frame'] = torch.tensor(c['boundary'], dtype=torch.int32)
+  if 'qframes' in c:  # query point = (t, position of the query track at frame t), data_loader.py:77-85
+    tq = torch.tensor(c['qframes'])[None].expand(c['B'], -1)
+    xyz = torch.gather(batch['query_tracks'], 2, tq[:, :, None, None].expand(c['B'], c['Q'], 1, 3))[:, :, 0]
+    batch['query_points'] = torch.cat([tq[..., None].float(), xyz], dim=-1)
   for k in ('dino_features', 'depth_features'):
     if k in batch:
       batch[k] = batch[k].bfloat16().float()

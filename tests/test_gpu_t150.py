@@ -2,7 +2,8 @@
 in-model S=151 fused attention, the pruned last blocks (single-query attention at S=151 / 129), the `crow_group=150` /
 `brow_group` row remaps, the window gather at t_q up to 149 (track_autoencoder_3d.py:239-245), the 12 352-wide query
 GEMM and the 600-wide head all run inside the model, for BASELINE configs[2] channels (C=772: xyz + depth 1 + DINO 768)
-and configs[1] channels (C=4: xyz + depth only).
+and configs[1] channels (C=4: xyz + depth only); case `c772_t300` is BASELINE configs[4]'s sequence length (T = T_out = 300:
+S = 301 fused attention, floor(t/150) in {0,1}, decoder window running off the 1152 latent channels).
 
 Expected values: tests/golden/t150_golden.npz, frozen from THIS REPO'S fp64 oracle by tests/golden/make_t150_golden.py
 (PARITY UNPINNED: the reference cannot run and holds no fixtures -- see that script's header).  Parameters / batches are
@@ -11,9 +12,9 @@ regenerated from seeds on both sides and verified by checksum before anything is
 Tolerances:
   fp32 mode : tracks / logits / latents max-abs <= 1e-4 (north_star), losses relative 2e-5, EVERY gradient leaf's norm
               within 5e-3 relative of the oracle's and the stored whole leaves <= 5e-3 relative Frobenius error.
-  bf16 mode : (what the benchmark runs) compared DIRECTLY with the fp64 oracle: tracks relative Frobenius <= 5e-2, losses
-              relative 5e-2, whole-gradient cosine >= 0.98, every leaf's norm within 20 % (bf16 activations through 11 blocks;
-              measured values are printed), stored leaves <= 0.25 relative error.  The `c772_tiles` case (M >= 16 384 rows, so
+  bf16 mode : (what the benchmark runs) compared DIRECTLY with the fp64 oracle: tracks / latents relative Frobenius <= 2e-2
+              (measured 7-9e-3), losses relative 5e-3 (measured ~2e-4), every leaf's norm within 12 % (measured <= 5 %; bf16
+              activations through 11 blocks), stored leaves <= 0.18 relative error (measured <= 8 %).  The `c772_tiles` case (M >= 16 384 rows, so
               the default dispatch takes the 8-phase / persistent kernels bench.py runs on) additionally compares every bf16
               gradient leaf with the library's own fp32 path.
 """
@@ -87,7 +88,7 @@ def _leaf_report(gf, exp, tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', ['c772', 'c4'])
+@pytest.mark.parametrize('case', ['c772', 'c4', 'c772_t300'])
 def test_t150_fp32_vs_oracle_golden(case):
   import spa3d
   cfg, p, batch, noise, exp = _case(case)
@@ -105,7 +106,7 @@ def test_t150_fp32_vs_oracle_golden(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', ['c772', 'c4'])
+@pytest.mark.parametrize('case', ['c772', 'c4', 'c772_t300'])
 def test_t150_bf16_vs_oracle_golden(case):
   """The benchmarked arithmetic (bf16 activations, default kernels) against the fp64 oracle directly."""
   import spa3d
@@ -115,12 +116,12 @@ def test_t150_bf16_vs_oracle_golden(case):
   e_l = rel_err(lat, torch.from_numpy(exp['latents']))
   got = [float(ld[k]) for k in ('total_loss', 'position_loss', 'visible_loss')]
   print(f'{case} bf16 T=150: tracks rel {e_t:.3e} latents rel {e_l:.3e} losses {got} vs {exp["losses"].tolist()}')
-  assert e_t < 5e-2 and e_l < 5e-2
-  assert abs(got[0] - exp['losses'][0]) < 5e-2 * abs(exp['losses'][0])
-  assert abs(got[1] - exp['losses'][1]) < 5e-2 * abs(exp['losses'][1])
+  assert e_t < 2e-2 and e_l < 2e-2          # measured 7-9e-3
+  assert abs(got[0] - exp['losses'][0]) < 5e-3 * abs(exp['losses'][0])   # measured 1.3-2.7e-4
+  assert abs(got[1] - exp['losses'][1]) < 5e-3 * abs(exp['losses'][1])
   names, rel, leaf = _leaf_report(gf, exp, f'{case} bf16')
-  assert float(rel.max()) < 0.20
-  assert max(leaf.values()) < 0.25
+  assert float(rel.max()) < 0.12            # measured 4-5e-2
+  assert max(leaf.values()) < 0.18          # measured 6-8e-2
   assert all(bool(torch.isfinite(gf[k]).all()) for k in names)
 
 
@@ -145,10 +146,10 @@ def test_t150_tiles_default_dispatch_bf16_and_fp32():
   e_b = rel_err(preds.tracks, torch.from_numpy(exp['tracks']))
   got = [float(ld[k]) for k in ('total_loss', 'position_loss', 'visible_loss')]
   print(f'{case} bf16: tracks rel {e_b:.3e} losses {got} vs {exp["losses"].tolist()}')
-  assert e_b < 5e-2
-  assert abs(got[0] - exp['losses'][0]) < 5e-2 * abs(exp['losses'][0])
+  assert e_b < 2e-2
+  assert abs(got[0] - exp['losses'][0]) < 5e-3 * abs(exp['losses'][0])
   names, rel, leaf = _leaf_report(gf, exp, f'{case} bf16')
-  assert float(rel.max()) < 0.20 and max(leaf.values()) < 0.25
+  assert float(rel.max()) < 0.05 and max(leaf.values()) < 0.15   # measured 1.3e-2 / 5.0e-2
   # per leaf, bf16 default kernels vs the fp32 path of the same library
   worst = ('', 0.0)
   for k in names:
@@ -156,8 +157,8 @@ def test_t150_tiles_default_dispatch_bf16_and_fp32():
     e = rel_err(gf[k], g32[k]) if n32 > 1e-12 else float(gf[k].abs().max())
     if e > worst[1]:
       worst = (k, e)
-    assert e < 0.25, (k, e)
+    assert e < 0.20, (k, e)   # measured worst 7.9e-2
   a = torch.cat([gf[k].double().reshape(-1) for k in names]); b = torch.cat([g32[k].double().reshape(-1) for k in names])
   cos = float((a @ b) / (a.norm() * b.norm()))
   print(f'{case}: worst bf16-vs-fp32 leaf {worst}, whole-gradient cosine {cos:.5f}')
-  assert cos > 0.99
+  assert cos > 0.999  # measured 0.99989
