@@ -144,7 +144,8 @@ struct spa3d_ctx {
   int hip_err = 0;
   int gemm_impl = 0;  // 0 auto, 1 generic only
   int attn_impl = 0;
-  float loss_scale = 1.f;  // backward runs at loss x loss_scale (fp16 mode: 4096), parameter gradients are scaled back at the end
+  float loss_scale = 1.f;  // the 16-bit backward runs at loss x scale, parameter gradients are scaled back at the end: 1 = off (bf16 / fp32),
+                           // > 0 a fixed scale, < 0 automatic with |loss_scale| the target head-gradient magnitude (fp16 mode: -16)
   int attn_bwd_mode = 0;  // fused attention backward structure: 0 auto, 1 four images + concurrent roles, 2 split-pass 4 waves (2 WG/CU), 3 split-pass 8 waves
   int nt_8p = 1;      // 8-phase kernels (256x256 / 128x384, counted vmcnt, staggered wave rows); 2 = also for small M, 0/3 = off
   int tn_8p = 1;      // 8-phase TN (dW) kernels; SPA3D_TN_8P=0 disables, =2 forces (tests)
@@ -235,7 +236,8 @@ template <typename T> void k_add(spa3d_ctx*, T* dst, const T* src, int64_t n);
 void k_fill(spa3d_ctx*, float* p, float v, int64_t n);
 void k_zero(spa3d_ctx*, void* p, int64_t bytes);
 void k_mul(spa3d_ctx*, float* a, const float* b, int64_t n);
-void k_scale(spa3d_ctx*, float* a, float s, int64_t n);
+void k_set_loss_scale(spa3d_ctx*, const float* denom_dev, float l1w, float setting, float* scale_dev);
+void k_unscale(spa3d_ctx*, float* a, const float* scale_dev, int64_t n);
 template <typename T> void k_cast_from_f32(spa3d_ctx*, const float* src, T* dst, int64_t n);
 template <typename T> void k_cast_to_f32(spa3d_ctx*, const T* src, float* dst, int64_t n);
 template <typename T> void k_pack(spa3d_ctx*, const float* src, int64_t src_ld, int rows, int cols, T* dst_native, int64_t ldn, T* dst_T, int64_t ldt);
@@ -264,7 +266,7 @@ void k_loss_fwd(spa3d_ctx*, const float* head, int64_t nq, int T_, const float* 
 void k_loss_from_preds(spa3d_ctx*, const float* tracks, const float* vlog, int64_t n, const float* tgt, const float* tvis, float* sums,
                        int NC = 3);
 template <typename T> void k_loss_bwd(spa3d_ctx*, const float* head, int64_t nq, int T_, const float* tgt, const float* tvis,
-                                      const float* denom_dev, float l1w, float bcew, T* dhead, int NC = 3);
+                                      const float* denom_dev, float l1w, float bcew, T* dhead, int NC = 3, const float* scale_dev = nullptr);
 void k_vis_count(spa3d_ctx*, const float* tvis, int64_t n, float* out);
 void k_set_denom(spa3d_ctx*, const float* sums, float denom_host, float* denom_dev);
 void k_loss_finalize(spa3d_ctx*, const float* sums, const float* denom_dev, float l1w, float bcew, float* loss3);

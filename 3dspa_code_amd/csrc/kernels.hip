@@ -965,13 +965,6 @@ void k_mul(spa3d_ctx* c, float* a, const float* b, int64_t n) {
   if (c->dry || n == 0) return;
   mul_kernel<<<GRID1D(n, 256), 256, 0, c->stream>>>(a, b, n); SPA_LAUNCH_CHECK(c);
 }
-__global__ void scale_kernel(float* __restrict__ a, float s, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a[i] *= s;
-}
-void k_scale(spa3d_ctx* c, float* a, float s, int64_t n) {
-  if (c->dry || n == 0) return;
-  scale_kernel<<<GRID1D(n, 256), 256, 0, c->stream>>>(a, s, n); SPA_LAUNCH_CHECK(c);
-}
 
 // ---------------------------------------------------------------------------------------------
 // D4-D6: readout sequence assembly without materialising tile/eye (track_autoencoder_3d.py:235-246,276-284)
@@ -1177,8 +1170,8 @@ void k_loss_finalize(spa3d_ctx* c, const float* sums, const float* denom_dev, fl
 template <typename T>
 __global__ void loss_bwd_kernel(const float* __restrict__ head, int64_t nq, int T_, const float* __restrict__ tgt,
                                 const float* __restrict__ tvis, const float* __restrict__ denom_dev, float l1w, float bcew, T* __restrict__ dhead,
-                                int NC) {
-  const float inv = 1.f / *denom_dev;
+                                int NC, const float* __restrict__ scale_dev) {
+  const float inv = (scale_dev ? *scale_dev : 1.f) / *denom_dev;  // scale_dev: the fp16 mode's loss scale (a power of two)
   const int64_t n = nq * 4 * T_;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     int64_t q = i / (4 * T_); int j = (int)(i - q * 4 * T_);
@@ -1198,10 +1191,30 @@ __global__ void loss_bwd_kernel(const float* __restrict__ head, int64_t nq, int 
 }
 template <typename T>
 void k_loss_bwd(spa3d_ctx* c, const float* head, int64_t nq, int T_, const float* tgt, const float* tvis, const float* denom_dev, float l1w,
-                float bcew, T* dhead, int NC) {
+                float bcew, T* dhead, int NC, const float* scale_dev) {
   if (c->dry || nq == 0) return;
-  loss_bwd_kernel<T><<<GRID1D(nq * 4 * T_, 256), 256, 0, c->stream>>>(head, nq, T_, tgt, tvis, denom_dev, l1w, bcew, dhead, NC);
+  loss_bwd_kernel<T><<<GRID1D(nq * 4 * T_, 256), 256, 0, c->stream>>>(head, nq, T_, tgt, tvis, denom_dev, l1w, bcew, dhead, NC, scale_dev);
   SPA_LAUNCH_CHECK(c);
+}
+// Loss scale of the 16-bit backward (fp16 mode).  setting > 0: that value.  setting < 0: automatic -- the largest power of two that keeps
+// the head gradient's magnitude l1w / denom at or below |setting| (16): activations' gradients then sit mid-range in fp16 for any batch
+// size (at BASELINE cfg#3, denom = 4.4 M: 8192; a 100-element toy batch: 1).
+__global__ void set_loss_scale_kernel(const float* __restrict__ denom_dev, float l1w, float setting, float* __restrict__ scale_dev) {
+  float s = setting;
+  if (setting < 0.f) s = fminf(fmaxf(exp2f(floorf(log2f(*denom_dev * (-setting) / l1w))), 1.f), 16777216.f);
+  *scale_dev = s;
+}
+void k_set_loss_scale(spa3d_ctx* c, const float* denom_dev, float l1w, float setting, float* scale_dev) {
+  if (c->dry) return;
+  set_loss_scale_kernel<<<1, 1, 0, c->stream>>>(denom_dev, l1w, setting, scale_dev); SPA_LAUNCH_CHECK(c);
+}
+__global__ void unscale_kernel(float* __restrict__ a, const float* __restrict__ scale_dev, int64_t n) {
+  const float s = 1.f / *scale_dev;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a[i] *= s;
+}
+void k_unscale(spa3d_ctx* c, float* a, const float* scale_dev, int64_t n) {
+  if (c->dry || n == 0) return;
+  unscale_kernel<<<GRID1D(n, 256), 256, 0, c->stream>>>(a, scale_dev, n); SPA_LAUNCH_CHECK(c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1302,7 +1315,7 @@ void k_uniform_noise(spa3d_ctx* c, float* out, int64_t n, uint32_t k0, uint32_t 
   template bool k_rank_bwd<T>(spa3d_ctx*, const T*, const T*, int64_t, int, int, int64_t, int, int, float*, float*);                                              \
   template void k_assemble_readout<T>(spa3d_ctx*, const T*, const T*, const int32_t*, int64_t, int, int, int, int, T*);                \
   template void k_assemble_readout_bwd<T>(spa3d_ctx*, const T*, const int32_t*, int64_t, int, int, int, int, T*, float*);              \
-  template void k_loss_bwd<T>(spa3d_ctx*, const float*, int64_t, int, const float*, const float*, const float*, float, float, T*, int);
+  template void k_loss_bwd<T>(spa3d_ctx*, const float*, int64_t, int, const float*, const float*, const float*, float, float, T*, int, const float*);
 INST(float)
 INST(bf16_t)
 

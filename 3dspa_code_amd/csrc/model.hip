@@ -468,7 +468,7 @@ template <typename T> struct Net {
       const int64_t mk = c->ar.mark();
       T* dhead = alloc<T>(nq * 4 * To);
       k_loss_bwd<T>(c, k.head, nq, To, b->query_tracks + b0 * k.Q * To * NC, b->query_tracks_visible + b0 * k.Q * To, denom_dev,
-                    L1_WEIGHT * c->loss_scale, BCE_WEIGHT * c->loss_scale, dhead, NC);  // loss_scale: 1 except in fp16 mode
+                    L1_WEIGHT, BCE_WEIGHT, dhead, NC, c->loss_scale != 1.f ? denom_dev + 2 : nullptr);  // + loss scale in fp16 mode
       lin_bwd_w(pred, k.q0n, dhead, nq);
       T* dq0n = alloc<T>(nq * dd);
       lin_bwd_x(pred, dhead, dq0n, nq);
@@ -560,6 +560,7 @@ void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
   if (train) {
     k_vis_count(c, b->query_tracks_visible, (int64_t)b->B * b->Q * To, sums + 2);
     k_set_denom(c, sums, a.denom, denom_dev);
+    if (c->loss_scale != 1.f) k_set_loss_scale(c, denom_dev, L1_WEIGHT, c->loss_scale, denom_dev + 2);  // sums[6]
     if (!a.accumulate) k_zero(c, a.G, c->nparams * 4);
   }
   for (int64_t b0 = 0; b0 < b->B; b0 += Bc) {
@@ -588,7 +589,7 @@ void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
     }
     c->ar.release(mk);
   }
-  if (train && c->loss_scale != 1.f) k_scale(c, a.G, 1.f / c->loss_scale, c->nparams);  // fp32 gradient buffer back to true scale
+  if (train && c->loss_scale != 1.f) k_unscale(c, a.G, denom_dev + 2, c->nparams);  // fp32 gradient buffer back to true scale (exact: power of two)
   if (train && a.loss3) k_loss_finalize(c, sums, denom_dev, L1_WEIGHT, BCE_WEIGHT, a.loss3);
 }
 
@@ -737,8 +738,9 @@ int spa3d_create(const spa3d_config* cfg, spa3d_handle* out) {
   c->cfg = *cfg;
   build_leaves(c);
   // fp16 gradients: activations' gradients of this loss sit at 1e-5..1e-7, below fp16's normal range (6.1e-5): the 16-bit backward runs
-  // at loss x 4096 and the fp32 parameter gradients are scaled back once at the end (static scale; exact for powers of two)
-  if (cfg->precision == SPA3D_F16) c->loss_scale = 4096.f;
+  // at loss x 2^k (k chosen per call from the loss denominator, k_set_loss_scale) and the fp32 parameter gradients are scaled back once
+  // at the end (exact for powers of two)
+  if (cfg->precision == SPA3D_F16) c->loss_scale = -16.f;
   const char* e = getenv("SPA3D_GEMM_IMPL"); if (e) c->gemm_impl = atoi(e);
   e = getenv("SPA3D_LOSS_SCALE"); if (e && cfg->precision == SPA3D_F16) c->loss_scale = (float)atof(e);
   e = getenv("SPA3D_ATTN_IMPL"); if (e) c->attn_impl = atoi(e);

@@ -109,8 +109,13 @@ def load_checkpoint(checkpoint_path: str, model=None, allow_pickle: bool = False
   entries, if present, under the keys 'opt_m', 'opt_v', 'step' are stripped -- use load_train_state for those)."""
   if not os.path.exists(checkpoint_path):
     raise FileNotFoundError(f'Checkpoint not found: {checkpoint_path}')
-  if not checkpoint_path.endswith('.npz'):
-    raise ValueError('only .npz checkpoints are supported (Flax msgpack needs flax, which is not available here)')
+  if not checkpoint_path.endswith('.npz'):  # Flax format (evaluate_tapvid3d.py:278-285, inference.py:490-503)
+    state_dict = restore_flax_checkpoint(checkpoint_path)
+    if 'params' in state_dict:
+      return state_dict['params']
+    if 'optimizer' in state_dict and isinstance(state_dict['optimizer'], dict) and 'target' in state_dict['optimizer']:
+      return state_dict['optimizer']['target']
+    return state_dict
   data = np.load(checkpoint_path, allow_pickle=allow_pickle)
   if 'params' in data.files:
     p = data['params']
@@ -123,6 +128,91 @@ def load_checkpoint(checkpoint_path: str, model=None, allow_pickle: bool = False
     flat = {k: np.array(data[k]) for k in data.files if not (k.startswith('opt_m/') or k.startswith('opt_v/') or k == 'step')}
     params = _unflatten_params(flat)
   return params
+
+
+# ------------------------------------------------------------------------------------------------ Flax msgpack checkpoints
+# `flax.training.checkpoints.restore_checkpoint(path, target=None)` (evaluate_tapvid3d.py:278, inference.py:490) restated: Flax is not
+# installed here and the reference holds no such file, so this follows Flax's documented serialization format -- PARITY UNPINNED:
+#   file      = msgpack(state_dict)                                  nested dicts with str keys
+#   ndarray   = ExtType(1, msgpack((shape, dtype_name, raw C-order bytes)))
+#   complex   = ExtType(2, msgpack((real, imag)))          np scalar = ExtType(3, same tuple as ndarray)
+#   arrays over 2**30 bytes are stored as {'__msgpack_chunked_array__': True, 'shape': [...], 'chunks': {'0': ndarray, '1': ...}}
+#   a checkpoint DIRECTORY holds files `<prefix><step>`; the largest step wins (natural ordering).
+_EXT_NDARRAY, _EXT_COMPLEX, _EXT_NPSCALAR = 1, 2, 3
+
+
+def _nd_from_bytes(data: bytes):
+  import msgpack
+  shape, dtype_name, buf = msgpack.unpackb(data, raw=True)
+  name = dtype_name.decode() if isinstance(dtype_name, bytes) else dtype_name
+  if name == 'bfloat16':  # not a NumPy dtype: widen exactly to float32
+    u16 = np.frombuffer(buf, dtype=np.uint16).astype(np.uint32) << 16
+    return u16.view(np.float32).reshape(tuple(shape))
+  return np.frombuffer(buf, dtype=np.dtype(name)).reshape(tuple(shape)).copy()
+
+
+def _ext_hook(code, data):
+  import msgpack
+  if code == _EXT_NDARRAY:
+    return _nd_from_bytes(data)
+  if code == _EXT_COMPLEX:
+    re_, im_ = msgpack.unpackb(data)
+    return complex(re_, im_)
+  if code == _EXT_NPSCALAR:
+    return _nd_from_bytes(data)[()]
+  return msgpack.ExtType(code, data)
+
+
+def _unchunk(tree):
+  if isinstance(tree, dict):
+    if tree.get('__msgpack_chunked_array__'):
+      chunks = [tree['chunks'][str(i)] for i in range(len(tree['chunks']))]
+      return np.concatenate([c.reshape(-1) for c in chunks]).reshape(tuple(tree['shape']))
+    return {k: _unchunk(v) for k, v in tree.items()}
+  return tree
+
+
+def msgpack_restore(raw: bytes):
+  """flax.serialization.msgpack_restore: bytes -> nested dict of NumPy arrays / scalars."""
+  import msgpack
+  return _unchunk(msgpack.unpackb(raw, ext_hook=_ext_hook, raw=False, strict_map_key=False))
+
+
+def msgpack_serialize(tree) -> bytes:
+  """flax.serialization.msgpack_serialize for nested dicts of arrays / Python scalars (arrays under 2**30 bytes)."""
+  import msgpack
+
+  def enc(o):
+    if isinstance(o, torch.Tensor):
+      o = o.detach().cpu().numpy()
+    if isinstance(o, np.ndarray):
+      if o.nbytes > 2**30:
+        raise ValueError('chunked arrays are not written (every 3DSPA leaf is far below 2**30 bytes)')
+      return msgpack.ExtType(_EXT_NDARRAY, msgpack.packb((list(o.shape), o.dtype.name, o.tobytes('C')), use_bin_type=True))
+    if isinstance(o, np.generic):
+      return msgpack.ExtType(_EXT_NPSCALAR, msgpack.packb(([], o.dtype.name, o.tobytes()), use_bin_type=True))
+    if isinstance(o, complex):
+      return msgpack.ExtType(_EXT_COMPLEX, msgpack.packb((o.real, o.imag)))
+    raise TypeError(f'cannot serialize {type(o)}')
+
+  return msgpack.packb(tree, default=enc, use_bin_type=True, strict_types=True)
+
+
+def restore_flax_checkpoint(ckpt_dir: str, prefix: str = 'checkpoint_'):
+  """checkpoints.restore_checkpoint(ckpt_dir, target=None): a file, or the newest `<prefix><step>` file of a directory."""
+  import re
+  path = ckpt_dir
+  if os.path.isdir(ckpt_dir):
+    def step_of(fn):
+      m = re.fullmatch(re.escape(prefix) + r'(\d+(?:\.\d+)?)', fn)
+      return float(m.group(1)) if m else None
+    cands = [(step_of(f), f) for f in os.listdir(ckpt_dir)]
+    cands = [c for c in cands if c[0] is not None]
+    if not cands:
+      raise ValueError(f'Checkpoint at {ckpt_dir} is empty or invalid')  # evaluate_tapvid3d.py:279-280
+    path = os.path.join(ckpt_dir, max(cands)[1])
+  with open(path, 'rb') as f:
+    return msgpack_restore(f.read())
 
 
 def load_train_state(checkpoint_path: str, state, rank0_only: bool = False):

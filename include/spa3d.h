@@ -42,7 +42,7 @@ extern "C" {
 #define SPA3D_F32 0  /* exact-fp32 path: v_mfma_f32_16x16x4_f32, fp32 activations (parity runs) */
 #define SPA3D_BF16 1 /* bf16 activations + bf16 MFMA, fp32 accumulate, fp32 master params/grads  */
 #define SPA3D_F16 2  /* IEEE fp16 activations + fp16 MFMA (same rate), fp32 accumulate / master params/grads; the 16-bit backward
-                        runs at loss x 4096 (static loss scale), BASELINE.json configs[4] */
+                        runs at loss x 2^k (k per call from the loss denominator), BASELINE.json configs[4] */
 
 typedef struct spa3d_ctx* spa3d_handle;
 

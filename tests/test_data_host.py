@@ -88,3 +88,49 @@ def test_train_state_resume_is_exact(spa3d, tmp_path):
   a = s1.train_step(batch, noise=noise)
   b = s2.train_step(batch, noise=noise)
   assert torch.allclose(s1.flat, s2.flat, atol=1e-7) and abs(float(a['train/loss']) - float(b['train/loss'])) < 1e-3 * abs(float(a['train/loss']))
+
+
+def test_tapvid3d_adapter_matches_the_reference_function(spa3d):
+  """PINNED: the fixture holds the outputs of the reference's own convert_predictions_to_tapvid3d_format, executed here by
+  tests/golden/make_tapvid_golden.py (ast-compiled from /root/reference/evaluate_tapvid3d.py:39-59, pure NumPy)."""
+  z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tapvid_adapter_golden.npz'), allow_pickle=False)
+  lg = torch.from_numpy(z['visible_logits'])
+  p = spa3d.TrackAutoEncoderResults(torch.from_numpy(z['tracks']), lg, torch.zeros_like(lg))
+  pt, occ = spa3d.convert_predictions_to_tapvid3d_format(p, torch.from_numpy(z['query_points']))
+  assert pt.dtype == z['pred_tracks'].dtype and np.array_equal(pt, z['pred_tracks'])
+  assert occ.dtype == np.bool_ and np.array_equal(occ, z['pred_occluded'])
+
+
+def test_flax_msgpack_checkpoint_reader(spa3d, tmp_path):
+  """Flax msgpack restore (evaluate_tapvid3d.py:278-285), PARITY UNPINNED (no Flax, no msgpack file in the reference): a byte string
+  assembled BY HAND from the msgpack spec + Flax's (shape, dtype, bytes) ndarray tuple, a bfloat16 leaf, the three state-dict layouts of
+  the loader, a checkpoint directory with several steps, and a round trip of the full MINI parameter tree."""
+  from importlib import import_module
+  D = import_module('3dspa_code_amd.data')
+  # {'a': float32[1] = [1.0]}: fixmap(1) 'a' ext8(len 17, type 1){ array3[ array1[1], str7 'float32', bin8(4) 00 00 80 3f ] }
+  raw = bytes([0x81, 0xa1, 0x61, 0xc7, 0x11, 0x01, 0x93, 0x91, 0x01, 0xa7]) + b'float32' + bytes([0xc4, 0x04, 0x00, 0x00, 0x80, 0x3f])
+  t = D.msgpack_restore(raw)
+  assert list(t) == ['a'] and t['a'].dtype == np.float32 and t['a'].tolist() == [1.0]
+  assert D.msgpack_serialize({'a': np.array([1.0], np.float32)}) == raw
+  import msgpack
+  bf = msgpack.ExtType(1, msgpack.packb(([2], 'bfloat16', np.array([0x3f80, 0xc000], np.uint16).tobytes()), use_bin_type=True))
+  assert D.msgpack_restore(msgpack.packb({'w': bf}, use_bin_type=True))['w'].tolist() == [1.0, -2.0]
+  cfg = O.Config(**MINI, use_dino=True, use_depth=True, dino_feature_dim=6, depth_feature_dim=2)
+  p = O.init_params(cfg, seed=3, depth_dim=2)
+  pn = O.tree_map(lambda v: v.numpy(), p)
+  d = tmp_path / 'ckpts'
+  d.mkdir()
+  (d / 'checkpoint_5').write_bytes(D.msgpack_serialize({'params': O.tree_map(lambda v: v * 0, pn), 'step': np.int64(5)}))
+  (d / 'checkpoint_12').write_bytes(D.msgpack_serialize({'params': pn, 'step': np.int64(12)}))
+  got = spa3d.load_checkpoint(str(d))  # directory: newest step wins; 'params' layout
+  for k, v in O.tree_flatten(p).items():
+    assert np.array_equal(O.tree_flatten(got)[k], v.numpy()), k
+  f2 = tmp_path / 'opt_layout'
+  f2.write_bytes(D.msgpack_serialize({'optimizer': {'target': pn, 'state': {'step': np.int64(1)}}}))
+  assert set(O.tree_flatten(spa3d.load_checkpoint(str(f2)))) == set(O.tree_flatten(p))
+  f3 = tmp_path / 'bare'
+  f3.write_bytes(D.msgpack_serialize(pn))
+  assert set(O.tree_flatten(spa3d.load_checkpoint(str(f3)))) == set(O.tree_flatten(p))
+  with pytest.raises(ValueError):
+    (tmp_path / 'empty').mkdir()
+    spa3d.load_checkpoint(str(tmp_path / 'empty'))

@@ -4,7 +4,7 @@ fp16-rounded inputs (a build that ran the bf16 MFMA on fp16 bit patterns would b
 against the oracle directly and against the frozen T=150 / T=300 goldens.
 
 Tolerances: fp16 keeps 11 significand bits (bf16: 8), so forward values are ~8x closer to the oracle than bf16's; the 16-bit backward
-runs at loss x 4096 (static loss scale, model.hip) and gradient contributions below 6e-8 x 1/4096 flush -- the BCE term at weight
+runs at loss x 2^k (k chosen per call so the head gradient's magnitude is <= 16, model.hip) and smaller contributions flush -- the BCE term at weight
 1e-8 (train.py:96) is such a contribution; leaves it alone feeds are compared by norm against a floor."""
 import ctypes as C
 import math
@@ -187,8 +187,8 @@ def test_fp16_full_size_vs_oracle_golden(case):
   e_t = rel_err(preds.tracks, torch.from_numpy(exp['tracks']))
   got = [float(ld[k]) for k in ('total_loss', 'position_loss', 'visible_loss')]
   print(f'{case} fp16: tracks rel {e_t:.3e} losses {got} vs {exp["losses"].tolist()}')
-  assert e_t < 1e-2
-  assert abs(got[0] - exp['losses'][0]) < 1e-2 * abs(exp['losses'][0])
+  assert e_t < 5e-3                                                    # measured 1.0-1.3e-3 (bf16: 7e-3)
+  assert abs(got[0] - exp['losses'][0]) < 1e-3 * abs(exp['losses'][0])  # measured 1-3e-5
   names, rel, leaf = T150._leaf_report(gf, exp, f'{case} fp16')
-  assert float(rel.max()) < 0.10 and max(leaf.values()) < 0.15
+  assert float(rel.max()) < 0.07 and max(leaf.values()) < 0.07         # measured 2.7e-3 (T=150), 2.7e-2 (T=300)
   assert all(bool(torch.isfinite(gf[k]).all()) for k in names)
