@@ -55,6 +55,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 constexpr int DH = 96, ROWB = DH * 2;  // 192-byte LDS rows
+constexpr bool fwd_wide(int KT, int NW) { return KT <= 10 || NW == 8; }
 
 // Block -> problem map.  The dispatcher deals blocks round-robin over the 8 XCDs (observed, speed only), so blocks b, b+8, ..
 // share an L2: give the i-th block of XCD label x head (i mod H) of sequence 8*(i div H) + x.  Bijective on [0, nseq*H); sequences
@@ -66,7 +67,8 @@ __device__ __forceinline__ int64_t map_prob(int64_t b, int64_t nseq, int H) {
   return ((i / H) * 8 + x) * H + (i % H);
 }
 
-// S rows of [*, 96] 16-bit elements (row stride ld elements): 4 threads per row, 24 elements each, RPP rows per pass
+// S rows of [*, 96] 16-bit elements (row stride ld elements): 4 threads per row, RPP rows per pass; thread `part` of a row holds its
+// 16-byte chunks part, part+4, part+8 (elements 8(part+4c)+j), so every wave-instruction moves 64 contiguous bytes of 16 rows
 template <int NP> struct RawRows { u16x8 x[NP][3]; };
 
 template <int NP, int RPP>
@@ -76,8 +78,8 @@ __device__ __forceinline__ void rows_load(RawRows<NP>& r, const bf16_t* __restri
   for (int ps = 0; ps < NP; ++ps) {
     const int row = r0 + RPP * ps;
     if (row < S) {
-      const u16x8* p = (const u16x8*)(src + (int64_t)row * ld_ + part * 24);
-      r.x[ps][0] = p[0]; r.x[ps][1] = p[1]; r.x[ps][2] = p[2];
+      const u16x8* p = (const u16x8*)(src + (int64_t)row * ld_) + part;  // chunks part, part+4, part+8: 64 contiguous bytes per row and instruction
+      r.x[ps][0] = p[0]; r.x[ps][1] = p[4]; r.x[ps][2] = p[8];
     } else {
 #pragma unroll
       for (int c = 0; c < 3; ++c)
@@ -104,11 +106,11 @@ __device__ __forceinline__ void rows_store(RawRows<NP>& r, int S_pad, const floa
 #pragma unroll
       for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r.x[ps][c][j] = f2bf(f[c * 8 + j] * rr * scale[part * 24 + c * 8 + j]);
+        for (int j = 0; j < 8; ++j) r.x[ps][c][j] = f2bf(f[c * 8 + j] * rr * scale[(part + 4 * c) * 8 + j]);
     }
     if (row < S_pad) {
-      u16x8* d = (u16x8*)(lds + row * ROWB + part * 48);
-      d[0] = r.x[ps][0]; d[1] = r.x[ps][1]; d[2] = r.x[ps][2];
+      u16x8* d = (u16x8*)(lds + row * ROWB) + part;
+      d[0] = r.x[ps][0]; d[4] = r.x[ps][1]; d[8] = r.x[ps][2];
     }
   }
 }
@@ -132,11 +134,34 @@ __device__ __forceinline__ void frag_norm(const u16x8 (&x)[3], const float* __re
   }
 }
 
+
+// Wave-private LDS tile (16 rows): results held as (row fr, d = 16dt + 4fq + r) -- 8 bytes per lane and dt, i.e. 32-byte pieces of 16
+// rows per store instruction -- are turned into 64 contiguous bytes per row and instruction (the staging loads' shape) on the way out.
+constexpr int WROW = 208;                 // tile row stride: 13 x 16 B (192-B rows would put 8 of a 16-lane group on one bank pair)
+constexpr int WTILE = 16 * WROW + 64;     // + 16 floats (the split-pass backward keeps the tile's row deltas there)
+__device__ __forceinline__ void tile_put(char* wt, int dt, u16x4 v) {
+  const int lane = threadIdx.x & 63;
+  *(u16x4*)(wt + (lane & 15) * WROW + (16 * dt + 4 * (lane >> 4)) * 2) = v;
+}
+__device__ __forceinline__ void tile_flush(const char* wt, bf16_t* g0, int64_t ld_, int nrows) {  // g0: row 0, column 0 of the tile in global memory
+  const int lane = threadIdx.x & 63, tr = lane >> 2, part = lane & 3;
+  asm volatile("" ::: "memory");
+  if (tr < nrows) {
+    const u16x8* sp = (const u16x8*)(wt + tr * WROW) + part;
+    u16x8* dp = (u16x8*)(g0 + (int64_t)tr * ld_) + part;
+    const u16x8 a = sp[0], b = sp[4], c = sp[8];
+    dp[0] = a; dp[4] = b; dp[8] = c;
+  }
+  asm volatile("" ::: "memory");
+}
+
 template <int KT, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs g) {
   constexpr int S_pad = KT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem; char* Vs = smem + S_pad * ROWB; float* kbias = (float*)(smem + 2 * S_pad * ROWB);
+  constexpr bool WIDE = fwd_wide(KT, NW);  // output rows through a wave tile (not where it would cost the second workgroup per CU)
+  char* wt = (char*)(kbias + S_pad) + (threadIdx.x >> 6) * WTILE;
   const int64_t prob = map_prob(blockIdx.x, g.nprob / g.H, g.H);
   const int64_t seq = prob / g.H; const int h = (int)(prob - seq * g.H);
   const int S = g.S, E = g.H * DH;
@@ -231,20 +256,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs g) {
           const uint4 vu = make_uint4(lo[s2].x, lo[s2].y, hi[s2].x, hi[s2].y);
           oacc = MFMA16(__builtin_bit_cast(mfma16x8, vu), pb[s2], oacc);
         }
-        if (q0 + fr < S) {
-          u16x4 o4;
+        u16x4 o4;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o4[r] = f2bf(oacc[r]);
-          *(u16x4*)(g.o + (seq * S + q0 + fr) * E + h * DH + dt * 16 + fq * 4) = o4;
-        }
+        for (int r = 0; r < 4; ++r) o4[r] = f2bf(oacc[r]);
+        if constexpr (WIDE) tile_put(wt, dt, o4);
+        else if (q0 + fr < S) *(u16x4*)(g.o + (seq * S + q0 + fr) * E + h * DH + dt * 16 + fq * 4) = o4;
       });
+      if constexpr (WIDE) tile_flush(wt, g.o + (seq * S + q0) * E + h * DH, E, S - q0);
     }
   }
 }
 
 template <int KT, int NW>
 static void launch_fwd(spa3d_ctx* c, const AttnArgs& a) {
-  const int lds = 2 * KT * 16 * ROWB + KT * 16 * 4;
+  const int lds = 2 * KT * 16 * ROWB + KT * 16 * 4 + (fwd_wide(KT, NW) ? NW * WTILE : 0);
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<KT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   attn_fwd_kernel<KT, NW><<<(unsigned)a.nprob, NW * 64, lds, c->stream>>>(a);
@@ -320,7 +345,8 @@ struct AttnBwdArgs {
 template <int KT>
 __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, const float* kbias, const float* scq,
                                                const mfma16x8 (&qb)[3], const mfma16x8 (&dob)[3], float mq, float lq, float dq_,
-                                               const u16x4 (&xraw)[6], bool valid, bf16_t* op, float (&ds_acc)[6][4]) {
+                                               const u16x4 (&xraw)[6], bool valid, char* wt, bf16_t* gtile, int64_t ld_, int nrows,
+                                               float (&ds_acc)[6][4]) {
   const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
   const float alpha = 0.10206207261596575f;  // 1/sqrt(96)
   mfma16x8 dsb[KT / 2];
@@ -387,19 +413,18 @@ __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, c
   }
   gx += __shfl_xor(gx, 16, 64); gx += __shfl_xor(gx, 32, 64);
   gx /= DH;
-  if (valid) {
 #pragma unroll
-    for (int dt = 0; dt < 6; ++dt) {
-      const f32x4 sc = *(const f32x4*)(scq + dt * 16 + fq * 4);
-      u16x4 o4;
+  for (int dt = 0; dt < 6; ++dt) {
+    const f32x4 sc = *(const f32x4*)(scq + dt * 16 + fq * 4);
+    u16x4 o4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        o4[r] = f2bf(rr * (dqa[dt][r] * sc[r] - x[dt][r] * gx));
-        ds_acc[dt][r] += dqa[dt][r] * x[dt][r];
-      }
-      *(u16x4*)(op + dt * 16) = o4;
+    for (int r = 0; r < 4; ++r) {
+      o4[r] = f2bf(rr * (dqa[dt][r] * sc[r] - x[dt][r] * gx));
+      if (valid) ds_acc[dt][r] += dqa[dt][r] * x[dt][r];
     }
+    tile_put(wt, dt, o4);
   }
+  tile_flush(wt, gtile, ld_, nrows);  // rows past the sequence end are never written
 }
 
 // (b) one 16-key tile against all queries.  kb / vb: this lane's key row as B-operand fragments (k^ normalised, v raw); kbv: its
@@ -407,8 +432,8 @@ __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, c
 template <int KT>
 __device__ __forceinline__ void bwd_key_tile(const char* Qs, const char* dOs, const float* mrow, const float* lrow,
                                              const float* drow, const float* sck, const mfma16x8 (&kb)[3], const mfma16x8 (&vb)[3],
-                                             float kbv, const u16x4 (&xraw)[6], bool valid, bf16_t* okp, bf16_t* ovp,
-                                             float (&ds_acc)[6][4]) {
+                                             float kbv, const u16x4 (&xraw)[6], bool valid, char* wt, bf16_t* gk, int64_t ldk_, bf16_t* gv,
+                                             int64_t ldv_, int nrows, float (&ds_acc)[6][4]) {
   const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
   const float alpha = 0.10206207261596575f;
   const bool keep = kbv == 0.f;
@@ -478,21 +503,26 @@ __device__ __forceinline__ void bwd_key_tile(const char* Qs, const char* dOs, co
   }
   gx += __shfl_xor(gx, 16, 64); gx += __shfl_xor(gx, 32, 64);
   gx /= DH;
-  if (valid) {
 #pragma unroll
-    for (int dt = 0; dt < 6; ++dt) {
-      const f32x4 sc = *(const f32x4*)(sck + dt * 16 + fq * 4);
-      u16x4 k4, v4;
+  for (int dt = 0; dt < 6; ++dt) {
+    const f32x4 sc = *(const f32x4*)(sck + dt * 16 + fq * 4);
+    u16x4 k4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        k4[r] = f2bf(rr * (dka[dt][r] * sc[r] - x[dt][r] * gx));
-        v4[r] = f2bf(dva[dt][r]);
-        ds_acc[dt][r] += dka[dt][r] * x[dt][r];
-      }
-      *(u16x4*)(okp + dt * 16) = k4;
-      *(u16x4*)(ovp + dt * 16) = v4;
+    for (int r = 0; r < 4; ++r) {
+      k4[r] = f2bf(rr * (dka[dt][r] * sc[r] - x[dt][r] * gx));
+      if (valid) ds_acc[dt][r] += dka[dt][r] * x[dt][r];
     }
+    tile_put(wt, dt, k4);
   }
+  tile_flush(wt, gk, ldk_, nrows);
+#pragma unroll
+  for (int dt = 0; dt < 6; ++dt) {
+    u16x4 v4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v4[r] = f2bf(dva[dt][r]);
+    tile_put(wt, dt, v4);
+  }
+  tile_flush(wt, gv, ldv_, nrows);
 }
 
 // dO rows + delta = rowsum(dO o O) into LDS
@@ -509,8 +539,8 @@ __device__ __forceinline__ void store_do_delta(const RawRows<NP>& xd, const RawR
       for (int j = 0; j < 8; ++j) dsum += bf2f(xd.x[ps][c][j]) * bf2f(xo.x[ps][c][j]);
     dsum += __shfl_xor(dsum, 1, 64); dsum += __shfl_xor(dsum, 2, 64);
     if (row < S_pad) {
-      u16x8* d = (u16x8*)(dOs + row * ROWB + part * 48);
-      d[0] = xd.x[ps][0]; d[1] = xd.x[ps][1]; d[2] = xd.x[ps][2];
+      u16x8* d = (u16x8*)(dOs + row * ROWB) + part;
+      d[0] = xd.x[ps][0]; d[4] = xd.x[ps][1]; d[8] = xd.x[ps][2];
       if (part == 0) drow[row] = dsum;
     }
   }
@@ -551,6 +581,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
   float* kbias = (float*)(dOs + S_pad * ROWB); float* mrow = kbias + S_pad; float* lrow = mrow + S_pad; float* drow = lrow + S_pad;
   float* sred = drow + S_pad;     // [2][96] scale-gradient staging
   float* sscale = sred + 2 * DH;  // [2][96] RMSNorm scales (LDS copies: as loop invariants in registers they cost 48 VGPRs)
+  char* wt = (char*)(sscale + 2 * DH) + (threadIdx.x >> 6) * WTILE;  // wave-private output tile
   const int S = g.S, E = g.H * DH;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, role = wv >> 2, w = wv & 3, fr = lane & 15, fq = lane >> 4;
   const int QT = (S + 15) / 16;
@@ -617,12 +648,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
           dob[s] = *(const mfma16x8*)(dOs + (q0 + fr) * ROWB + (s * 32 + fq * 8) * 2);
         }
 #ifdef SPA3D_ABLATE
-        const bool valid_st = valid && !(g.ablate & 4);
+        const int nrows_st = (g.ablate & 4) ? 0 : S - q0;
 #else
-        const bool valid_st = valid;
+        const int nrows_st = S - q0;
 #endif
-        bwd_query_tile<KT>(Ks, Vs, kbias, sscale, qb, dob, mrow[q0 + fr], lrow[q0 + fr], drow[q0 + fr], xraw, valid_st,
-                           g.dq + (seq * S + qrow) * g.ldq + h * DH + fq * 4, ds_acc);
+        bwd_query_tile<KT>(Ks, Vs, kbias, sscale, qb, dob, mrow[q0 + fr], lrow[q0 + fr], drow[q0 + fr], xraw, valid, wt,
+                           g.dq + (seq * S + q0) * g.ldq + h * DH, g.ldq, nrows_st, ds_acc);
       }
     } else {          // ------------------------------------------------------------------ (b) key tiles -> dk, dv
       for (int kt = w; kt < QT; kt += 4) {  // real key tiles only (S_q == S_k)
@@ -641,12 +672,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
           vb[s] = *(const mfma16x8*)(Vs + (k0 + fr) * ROWB + (s * 32 + fq * 8) * 2);
         }
 #ifdef SPA3D_ABLATE
-        const bool valid_st = valid && !(g.ablate & 4);
+        const int nrows_st = (g.ablate & 4) ? 0 : S - k0;
 #else
-        const bool valid_st = valid;
+        const int nrows_st = S - k0;
 #endif
-        bwd_key_tile<KT>(Qs, dOs, mrow, lrow, drow, sscale + DH, kb, vb, kbias[k0 + fr], xraw, valid_st,
-                         g.dk + (seq * S + krow) * g.ldk + h * DH + fq * 4, g.dv + (seq * S + krow) * g.ldv + h * DH + fq * 4, ds_acc);
+        bwd_key_tile<KT>(Qs, dOs, mrow, lrow, drow, sscale + DH, kb, vb, kbias[k0 + fr], xraw, valid, wt, g.dk + (seq * S + k0) * g.ldk + h * DH,
+                         g.ldk, g.dv + (seq * S + k0) * g.ldv + h * DH, g.ldv, nrows_st, ds_acc);
       }
     }
   }
@@ -661,8 +692,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_split_kernel(AttnBwdArgs 
   char* B0 = smem; char* B1 = B0 + S_pad * ROWB;  // pass A: K^, V ; pass B: Q^, dO
   float* kbias = (float*)(B1 + S_pad * ROWB); float* mrow = kbias + S_pad; float* lrow = mrow + S_pad; float* drow = lrow + S_pad;
   float* sred = drow + S_pad; float* sscale = sred + 2 * DH;
-  constexpr int WTILE = 16 * ROWB + 64;  // wave-private: 16 rows + 16 deltas
-  char* wtile = (char*)(sscale + 2 * DH);
+  char* wtile = (char*)(sscale + 2 * DH);  // wave-private tiles: own-row staging in pass A, output rows in both passes
   const int S = g.S, E = g.H * DH;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fq = lane >> 4;
   const int QT = (S + 15) / 16;
@@ -703,18 +733,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_split_kernel(AttnBwdArgs 
       const int64_t grow = seq * S + (q0 + tr < S ? q0 + tr : S - 1);
       u16x8 xq[3], xd[3], xo[3]; u16x4 xraw[6];
       {
-        const u16x8* pq = (const u16x8*)(g.q + grow * g.ldq + h * DH + part * 24);
-        const u16x8* pd = (const u16x8*)(g.d_o + grow * E + h * DH + part * 24);
-        const u16x8* po = (const u16x8*)(g.o + grow * E + h * DH + part * 24);
+        const u16x8* pq = (const u16x8*)(g.q + grow * g.ldq + h * DH) + part;
+        const u16x8* pd = (const u16x8*)(g.d_o + grow * E + h * DH) + part;
+        const u16x8* po = (const u16x8*)(g.o + grow * E + h * DH) + part;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { xq[c] = pq[c]; xd[c] = pd[c]; xo[c] = po[c]; }
+        for (int c = 0; c < 3; ++c) { xq[c] = pq[4 * c]; xd[c] = pd[4 * c]; xo[c] = po[4 * c]; }
         const bf16_t* xp = g.q + (seq * S + qrow) * g.ldq + h * DH + fq * 4;
 #pragma unroll
         for (int dt = 0; dt < 6; ++dt) xraw[dt] = *(const u16x4*)(xp + dt * 16);
       }
       float mq = 0.f, lq = __builtin_inff();  // padding query: P = exp(.. - inf) = 0
       if (valid) { mq = g.lse[(prob * S + qrow) * 2]; lq = g.lse[(prob * S + qrow) * 2 + 1]; }
-      char* wt = wtile + w * WTILE; float* wdel = (float*)(wt + 16 * ROWB);
+      char* wt = wtile + w * WTILE; float* wdel = (float*)(wt + 16 * WROW);
       mfma16x8 qb[3], dob[3];
       {  // q^ rows -> tile -> fragments
         float f[24]; float ss = 0.f;
@@ -727,9 +757,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_split_kernel(AttnBwdArgs 
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) xq[c][j] = f2bf(f[c * 8 + j] * rr * sscale[part * 24 + c * 8 + j]);
-        u16x8* d = (u16x8*)(wt + tr * ROWB + part * 48);
-        d[0] = xq[0]; d[1] = xq[1]; d[2] = xq[2];
+          for (int j = 0; j < 8; ++j) xq[c][j] = f2bf(f[c * 8 + j] * rr * sscale[(part + 4 * c) * 8 + j]);
+        u16x8* d = (u16x8*)(wt + tr * ROWB) + part;
+        d[0] = xq[0]; d[4] = xq[1]; d[8] = xq[2];
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int s = 0; s < 3; ++s) qb[s] = *(const mfma16x8*)(wt + fr * ROWB + (s * 32 + fq * 8) * 2);
@@ -742,8 +772,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_split_kernel(AttnBwdArgs 
 #pragma unroll
           for (int j = 0; j < 8; ++j) dsum += bf2f(xd[c][j]) * bf2f(xo[c][j]);
         dsum += __shfl_xor(dsum, 1, 64); dsum += __shfl_xor(dsum, 2, 64);
-        u16x8* d = (u16x8*)(wt + tr * ROWB + part * 48);
-        d[0] = xd[0]; d[1] = xd[1]; d[2] = xd[2];
+        u16x8* d = (u16x8*)(wt + tr * ROWB) + part;
+        d[0] = xd[0]; d[4] = xd[1]; d[8] = xd[2];
         if (part == 0) wdel[tr] = dsum;
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -751,7 +781,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_split_kernel(AttnBwdArgs 
         dsum = wdel[fr];
         asm volatile("" ::: "memory");
       }
-      bwd_query_tile<KT>(B0, B1, kbias, sscale, qb, dob, mq, lq, dsum, xraw, valid, g.dq + (seq * S + qrow) * g.ldq + h * DH + fq * 4,
+      bwd_query_tile<KT>(B0, B1, kbias, sscale, qb, dob, mq, lq, dsum, xraw, valid, wt, g.dq + (seq * S + q0) * g.ldq + h * DH, g.ldq, S - q0,
                          dsq_acc);
     }
     // ================================================================== pass B: Q^, dO resident; key tiles -> dk, dv
@@ -785,8 +815,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_split_kernel(AttnBwdArgs 
 #pragma unroll
       for (int s = 0; s < 3; ++s) vb[s] = __builtin_bit_cast(mfma16x8, vx[s]);
       const float kbv = kbias[k0 + fr];  // written in pass A, untouched since
-      bwd_key_tile<KT>(B0, B1, mrow, lrow, drow, sscale + DH, kb, vb, kbv, xraw, valid, g.dk + (seq * S + krow) * g.ldk + h * DH + fq * 4,
-                       g.dv + (seq * S + krow) * g.ldv + h * DH + fq * 4, dsk_acc);
+      bwd_key_tile<KT>(B0, B1, mrow, lrow, drow, sscale + DH, kb, vb, kbv, xraw, valid, wtile + w * WTILE, g.dk + (seq * S + k0) * g.ldk + h * DH,
+                       g.ldk, g.dv + (seq * S + k0) * g.ldv + h * DH, g.ldv, S - k0, dsk_acc);
     }
   }
   flush_scale_grads<NTH>(g, sred, dsq_acc, dsk_acc, true, true);
@@ -796,8 +826,8 @@ template <int KT>
 static void launch_bwd(spa3d_ctx* c, const AttnBwdArgs& a) {
   constexpr int S_pad = KT * 16;
   const int small = 4 * S_pad * 4 + 4 * DH * 4;
-  const int lds4 = 4 * S_pad * ROWB + small;
-  auto lds2 = [&](int nw) { return 2 * S_pad * ROWB + small + nw * (16 * ROWB + 64); };
+  const int lds4 = 4 * S_pad * ROWB + small + 8 * WTILE;
+  auto lds2 = [&](int nw) { return 2 * S_pad * ROWB + small + nw * WTILE; };
   // mode 1: four resident images, concurrent roles (S <= 192); 2: split-pass, 4 waves, two workgroups per CU; 3: split-pass, 8 waves
   int mode = c->attn_bwd_mode;
   if (S_pad > 192) mode = 3;

@@ -9,7 +9,7 @@ import importlib
 b = importlib.import_module('3dspa_code_amd.build')
 out = os.path.join(ROOT, 'tools', '_ablate'); os.makedirs(out, exist_ok=True)
 b.build(verbose=False)
-objs = [os.path.join(b.HERE, 'build', s.replace('.hip', '.o')) for s in b.SOURCES if s != 'attention_fused.hip']
+objs = [os.path.join(b.HERE, 'build', o) for o in sorted(os.listdir(os.path.join(b.HERE, 'build'))) if o.endswith('.o') and o != 'attention_fused.o']
 ao = os.path.join(out, 'attention_fused_ablate.o')
 subprocess.check_call([b._hipcc()] + b.FLAGS + ['-DSPA3D_ABLATE', '-c', os.path.join(b.CSRC, 'attention_fused.hip'), '-o', ao])
 lib_path = os.path.join(out, 'libspa3d_ablate.so')
