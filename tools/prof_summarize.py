@@ -4,7 +4,7 @@
 usage: prof_summarize.py results.db out_prefix"""
 import re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); out = sys.argv[2]
-short = lambda n: re.sub(r'\(.*', '', n).replace('void ', '').strip()
+short = lambda n: re.sub(r'\(.*', '', n).replace('void ', '').replace('h_bf16::', '').replace('h_f16::', 'f16:').strip()
 rows = db.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3 from kernels group by name order by 3 desc").fetchall()
 if rows:
   tot = sum(r[2] for r in rows)

@@ -14,6 +14,7 @@ run() {  # name, rocprof args...
   rocprofv3 "$@" -d $OUT/$name -o $name -- python3 $REPO/bench.py --steps ${STEPS:-1} --warmup 1 --no-cpu-baseline > $OUT/$name.log 2>&1
   local db=$(find $OUT/$name -name '*.db' | head -1)
   python3 $REPO/tools/prof_summarize.py $db $OUT/$name
+  rm -rf $OUT/$name   # the rocpd databases are hundreds of MB: only the summaries travel back
   echo "$name done"; tail -c 300 $OUT/$name.log | head -c 300; echo
 }
 STEPS=2 run trace --kernel-trace --stats
