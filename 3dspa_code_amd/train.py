@@ -30,20 +30,28 @@ def create_learning_rate_schedule(base_lr: float, warmup_steps: int, total_steps
   return schedule
 
 
-def global_visible_count(visible: torch.Tensor, group=None) -> float:
+def _collectives_on(group=None, force=False) -> bool:
+  """True when the step's collectives must run: more than one rank, or `force` (world size 1: the reductions are identities, but the
+  RCCL path -- communicator, device buffers, bucketed async all-reduce -- is exercised end to end; tests/test_gpu_rccl.py)."""
+  if not (dist.is_available() and dist.is_initialized()):
+    return False
+  return force or dist.get_world_size(group) > 1
+
+
+def global_visible_count(visible: torch.Tensor, group=None, force=False) -> float:
   """max(sum(query_tracks_visible) over ALL ranks, 1): both loss terms divide by the batch-global visible count
   (train.py:111-113,119-121), so under data parallelism it is one scalar all-reduce BEFORE the backward.  The C-ABI takes the
   denominator by value, so this is one 4-byte device->host read per step (the only host sync of the multi-GPU step)."""
   s = visible.to(torch.float32).sum()
-  if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+  if _collectives_on(group, force):
     dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
   return max(float(s.item()), 1.0)
 
 
-def allreduce_flat_(flat: torch.Tensor, bucket_elems: int, group=None, extra=()):
+def allreduce_flat_(flat: torch.Tensor, bucket_elems: int, group=None, extra=(), force=False):
   """In-place SUM all-reduce of a flat buffer in a few large buckets (RCCL ring: per-link xGMI bound, so few and
   large), all in flight together; `extra` small tensors ride along.  Returns when every bucket has been reduced."""
-  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+  if not _collectives_on(group, force):
     return
   works = []
   n = flat.numel()
@@ -55,10 +63,10 @@ def allreduce_flat_(flat: torch.Tensor, bucket_elems: int, group=None, extra=())
     w.wait()
 
 
-def broadcast_state_(tensors, src: int = 0, group=None):
+def broadcast_state_(tensors, src: int = 0, group=None, force=False):
   """Replicas must start from rank `src`'s parameters and Adam moments whatever each rank initialised or loaded
   (a checkpoint read on rank 0 only, different seeds): one broadcast per buffer at construction / resume."""
-  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+  if not _collectives_on(group, force):
     return
   for t in tensors:
     dist.broadcast(t, src=src, group=group)
@@ -84,7 +92,7 @@ class TrainState:
   def __init__(self, model: TrackAutoEncoder3D, params, learning_rate: float = 1e-4, warmup_steps: int = 10000,
                total_steps: int = 1000000, weight_decay: float = 0.01, clip_norm: float = 1.0, b1: float = 0.9,
                b2: float = 0.999, eps: float = 1e-8, process_group: Optional[dist.ProcessGroup] = None,
-               grad_bucket_bytes: int = 128 << 20, compute=None, adamw=None, noise_fn=None):
+               grad_bucket_bytes: int = 128 << 20, compute=None, adamw=None, noise_fn=None, force_collectives: bool = False):
     self.model = model
     self.params = params if hasattr(params, 'flat') and params.flat is not None else None
     flat = model.flat_from_tree(params)
@@ -104,6 +112,7 @@ class TrainState:
     self.world = dist.get_world_size(process_group) if on else 1
     self.rank = dist.get_rank(process_group) if on else 0
     self.bucket_elems = max(1, grad_bucket_bytes // 4)
+    self.force = bool(force_collectives) and on  # run the collectives at world size 1 too (RCCL smoke test)
     self._compute = compute or self._hip_compute
     self._adamw = adamw or self._hip_adamw
     self._noise_fn = noise_fn or _hip_uniform_noise
@@ -112,7 +121,7 @@ class TrainState:
 
   def sync_from_rank0(self):
     """parameters + Adam moments of every replica := rank 0's (also after load_train_state on rank 0 only)"""
-    broadcast_state_((self.flat, self.m, self.v), 0, self.pg)
+    broadcast_state_((self.flat, self.m, self.v), 0, self.pg, self.force)
 
   # ---- default (HIP) compute and optimizer
   def _hip_compute(self, params, batch, grads_flat, denom, discretize, noise):
@@ -135,14 +144,15 @@ class TrainState:
     return self._noise_cache[key]
 
   def train_step(self, batch, discretize: bool = True, noise=None):
-    denom = global_visible_count(batch['query_tracks_visible'], self.pg) if self.world > 1 else 0.0
-    if self.world > 1 and discretize and noise is None:
+    multi = self.world > 1 or self.force
+    denom = global_visible_count(batch['query_tracks_visible'], self.pg, self.force) if multi else 0.0
+    if multi and discretize and noise is None:
       noise = self.rank_noise(batch['query_tracks_visible'].shape[0])
     ld = self._compute(self.params, batch, self.grads, denom, discretize, noise)
     l3 = torch.stack([torch.as_tensor(ld[k], dtype=torch.float32, device=self.flat.device).reshape(())
                       for k in ('total_loss', 'position_loss', 'visible_loss')])
     # the per-rank gradients and loss terms already carry the global 1/denominator -> plain SUM over ranks
-    allreduce_flat_(self.grads, self.bucket_elems, self.pg, extra=(l3,))
+    allreduce_flat_(self.grads, self.bucket_elems, self.pg, extra=(l3,), force=self.force)
     lr = self.schedule(self.step)
     self._adamw(self.flat, self.grads, self.m, self.v, lr, self.step, self.clip, self.b1, self.b2, self.eps, self.wd, self.scratch)
     self.step += 1

@@ -25,7 +25,7 @@ for line in open(path):
   a = agg[(int(cls), int(m), int(n), int(k), int(fl2))]
   a[0] += 1; a[1] += float(ms); a[2] += float(fl); a[3] += float(by)
 tot = sum(a[1] for a in agg.values())
-names = {0: 'NT', 1: 'TN', 2: 'generic', 3: 'attn_fwd', 4: 'attn_bwd'}
+names = {0: 'NT', 1: 'TN', 2: 'generic', 3: 'attn_fwd', 4: 'attn_bwd', 5: 'ln_fwd', 6: 'ln_bwd', 7: 'attn_q1'}
 print(f'total profiled ms {tot:.1f}')
 for key, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
   cls, m, n, k, f = key
