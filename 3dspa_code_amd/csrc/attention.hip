@@ -11,10 +11,11 @@ namespace SPA_NS {
 
 bool attn_fused_fwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ldq, int64_t ldk, int64_t ldv,
                          const float* sq, const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, bf16_t* o,
-                         float* lse);
+                         float* lse, const int32_t* seq_off, int64_t total_rows);
 bool attn_fused_bwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ldq, int64_t ldk, int64_t ldv,
                          const float* sq, const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, const bf16_t* o,
-                         const float* lse, const bf16_t* d_o, bf16_t* dq, bf16_t* dk, bf16_t* dv, float* dsq, float* dsk);
+                         const float* lse, const bf16_t* d_o, bf16_t* dq, bf16_t* dk, bf16_t* dv, float* dsq, float* dsk,
+                         const int32_t* seq_off, int64_t total_rows);
 
 template <typename T> static T* aalloc(spa3d_ctx* c, int64_t n) { return (T*)c->ar.alloc(n * (int64_t)sizeof(T)); }
 
@@ -37,11 +38,13 @@ static void scores(spa3d_ctx* c, const T* qn, const T* kn, T* s, int64_t ns, int
 
 template <typename T>
 void attention_fwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq, const float* sk,
-              const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, T* o, float* lse, int impl) {
+              const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, T* o, float* lse, int impl, const int32_t* seq_off,
+              int64_t total_rows) {
   const int E = H * Dh;
   if constexpr (sizeof(T) == 2) {
-    if (impl != 1 && attn_fused_fwd_bf16(c, q, k, v, ldq, ldk, ldv, sq, sk, km, nseq, Sq, Sk, H, Dh, o, lse)) return;
+    if (impl != 1 && attn_fused_fwd_bf16(c, q, k, v, ldq, ldk, ldv, sq, sk, km, nseq, Sq, Sk, H, Dh, o, lse, seq_off, total_rows)) return;
   }
+  if (seq_off) { if (!c->hip_err) { c->hip_err = -2; c->err = "ragged sequences need the fused attention kernels"; } return; }
   if (impl == 2) { if (!c->hip_err) { c->hip_err = -2; c->err = "fused attention forward does not cover this shape/dtype"; } return; }
   const int64_t cs = attn_chunk(nseq, Sq, Sk, H, E, (int)sizeof(T));
   int64_t mk = c->ar.mark();
@@ -64,12 +67,14 @@ void attention_fwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq
 template <typename T>
 void attention_bwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq, const float* sk,
               const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, const T* o, const float* lse, const T* d_o, T* dq, T* dk,
-              T* dv, float* dsq, float* dsk, int impl) {
+              T* dv, float* dsq, float* dsk, int impl, const int32_t* seq_off, int64_t total_rows) {
   const int E = H * Dh;
   if constexpr (sizeof(T) == 2) {
     if (impl != 1 && o && lse &&
-        attn_fused_bwd_bf16(c, q, k, v, ldq, ldk, ldv, sq, sk, km, nseq, Sq, Sk, H, Dh, o, lse, d_o, dq, dk, dv, dsq, dsk)) return;
+        attn_fused_bwd_bf16(c, q, k, v, ldq, ldk, ldv, sq, sk, km, nseq, Sq, Sk, H, Dh, o, lse, d_o, dq, dk, dv, dsq, dsk, seq_off, total_rows))
+      return;
   }
+  if (seq_off) { if (!c->hip_err) { c->hip_err = -2; c->err = "ragged sequences need the fused attention kernels"; } return; }
   if (impl == 2) { if (!c->hip_err) { c->hip_err = -2; c->err = "fused attention backward does not cover this shape/dtype"; } return; }
   const int64_t cs = attn_chunk(nseq, Sq, Sk, H, E, (int)sizeof(T));
   int64_t mk = c->ar.mark();
@@ -123,9 +128,10 @@ void attention_bwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq
 
 #define INST_ATTN(T)                                                                                                                  \
   template void attention_fwd<T>(spa3d_ctx*, const T*, const T*, const T*, int64_t, int64_t, int64_t, const float*, const float*,     \
-                                 const float*, int64_t, int, int, int, int, T*, float*, int);                                                \
+                                 const float*, int64_t, int, int, int, int, T*, float*, int, const int32_t*, int64_t);                       \
   template void attention_bwd<T>(spa3d_ctx*, const T*, const T*, const T*, int64_t, int64_t, int64_t, const float*, const float*,     \
-                                 const float*, int64_t, int, int, int, int, const T*, const float*, const T*, T*, T*, T*, float*, float*, int);
+                                 const float*, int64_t, int, int, int, int, const T*, const float*, const T*, T*, T*, T*, float*, float*, int, \
+                                 const int32_t*, int64_t);
 INST_ATTN(float)
 INST_ATTN(bf16_t)
 }  // namespace SPA_NS

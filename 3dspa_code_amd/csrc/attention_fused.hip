@@ -37,6 +37,8 @@ struct AttnArgs {
   const float *sq, *sk, *km;
   int S, H; int64_t nprob;
   bf16_t* o; float* lse;  // o [nseq*S][H*96]; lse [nseq][H][S][2] = (row max, log row sum) (may be null)
+  const int32_t* seq_off;  // null: dense sequences of S rows.  Else ragged (token pruning): sequence i = rows [seq_off[i], seq_off[i+1]) of q/k/v/o,
+                           // at most S of them; lse of (sequence, head, t) sits at ((seq_off[i] * H + h * S_i) + t) * 2 either way
 };
 
 // transposed LDS read with a compile-time byte offset in the instruction: as separate addresses every one is a loop-invariant
@@ -164,20 +166,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs g) {
   char* wt = (char*)(kbias + S_pad) + (threadIdx.x >> 6) * WTILE;
   const int64_t prob = map_prob(blockIdx.x, g.nprob / g.H, g.H);
   const int64_t seq = prob / g.H; const int h = (int)(prob - seq * g.H);
-  const int S = g.S, E = g.H * DH;
+  const int64_t row0 = g.seq_off ? (int64_t)g.seq_off[seq] : seq * g.S;       // first row of the sequence
+  const int S = g.seq_off ? g.seq_off[seq + 1] - (int)row0 : g.S, E = g.H * DH;  // its length (wave-uniform)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fq = lane >> 4;
   const int QT = (S + 15) / 16;
 
   constexpr int RPP = NW * 16, NP = (S_pad + RPP - 1) / RPP, NT = (KT + NW - 1) / NW;
   // every global load of the problem is in flight before the first use: K rows, V rows, this wave's Q fragments
   RawRows<NP> rk, rv;
-  rows_load<NP, RPP>(rk, g.k + seq * S * g.ldk + h * DH, g.ldk, S);
-  rows_load<NP, RPP>(rv, g.v + seq * S * g.ldv + h * DH, g.ldv, S);
+  rows_load<NP, RPP>(rk, g.k + row0 * g.ldk + h * DH, g.ldk, S);
+  rows_load<NP, RPP>(rv, g.v + row0 * g.ldv + h * DH, g.ldv, S);
   u16x8 qx[NT][3];
 #pragma unroll
   for (int it = 0; it < NT; ++it) {
     int qrow = (w + NW * it) * 16 + fr; if (qrow > S - 1) qrow = S - 1;
-    const bf16_t* qp = g.q + (seq * S + qrow) * g.ldq + h * DH + fq * 8;
+    const bf16_t* qp = g.q + (row0 + qrow) * g.ldq + h * DH + fq * 8;
 #pragma unroll
     for (int s = 0; s < 3; ++s) qx[it][s] = *(const u16x8*)(qp + s * 32);
   }
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs g) {
   for (int t = tid; t < S_pad; t += NW * 64) {
     float b = 0.f;
     if (t >= S) b = -__builtin_inff();                           // padding key: weight exactly 0
-    else if (g.km && g.km[seq * S + t] == 0.f) b = NEG_BIG;      // where(mask, logit, finfo.min)
+    else if (g.km && g.km[row0 + t] == 0.f) b = NEG_BIG;      // where(mask, logit, finfo.min)
     kbias[t] = b;
   }
   __syncthreads();
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs g) {
         for (int r = 0; r < 4; ++r) { const float p = __expf(acc[kt][r] - m); acc[kt][r] = p; l += p; }
       l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
       const float inv = 1.f / l;
-      if (g.lse && fq == 0 && q0 + fr < S) { float* lp = g.lse + (prob * S + q0 + fr) * 2; lp[0] = m; lp[1] = __logf(l); }
+      if (g.lse && fq == 0 && q0 + fr < S) { float* lp = g.lse + (row0 * g.H + (int64_t)h * S + q0 + fr) * 2; lp[0] = m; lp[1] = __logf(l); }
       // ---- P^T as B operands: k-step s2 covers key tiles 2*s2, 2*s2+1; element j <-> key 16*(2*s2 + (j>>2)) + 4*fq + (j&3)
       mfma16x8 pb[KT / 2];
 #pragma unroll
@@ -260,9 +263,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) o4[r] = f2bf(oacc[r]);
         if constexpr (WIDE) tile_put(wt, dt, o4);
-        else if (q0 + fr < S) *(u16x4*)(g.o + (seq * S + q0 + fr) * E + h * DH + dt * 16 + fq * 4) = o4;
+        else if (q0 + fr < S) *(u16x4*)(g.o + (row0 + q0 + fr) * E + h * DH + dt * 16 + fq * 4) = o4;
       });
-      if constexpr (WIDE) tile_flush(wt, g.o + (seq * S + q0) * E + h * DH, E, S - q0);
+      if constexpr (WIDE) tile_flush(wt, g.o + (row0 + q0) * E + h * DH, E, S - q0);
     }
   }
 }
@@ -282,15 +285,16 @@ constexpr int ATTN_MAX_S = 320;  // K^ and V of one head resident: 2 x 320 x 192
 // returns false when the shape is outside what the fused kernels cover (the caller then composes the generic kernels)
 bool attn_fused_fwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ldq, int64_t ldk, int64_t ldv,
                          const float* sq, const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, bf16_t* o,
-                         float* lse) {
+                         float* lse, const int32_t* seq_off, int64_t total_rows) {
   if (Dh != DH || Sq != Sk || Sk < 2 || Sk > ATTN_MAX_S) return false;
   if (ldq % 8 || ldk % 8 || ldv % 8 || !al16(q) || !al16(k) || !al16(v) || !al16(o)) return false;
   if (nseq * H > 0x7fffffffLL) return false;
   if (c->dry) return true;
   AttnArgs a; a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.sq = sq; a.sk = sk; a.km = km;
-  a.S = Sk; a.H = H; a.nprob = nseq * H; a.o = o; a.lse = lse;
+  a.S = Sk; a.H = H; a.nprob = nseq * H; a.o = o; a.lse = lse; a.seq_off = seq_off;
+  const double rows = total_rows > 0 ? (double)total_rows : (double)nseq * Sk;  // ragged: rows actually present
   const int KT = ((Sk + 31) / 32) * 2;
-  ProfScope ps(c, PROF_ATTN_FWD, 4.0 * (double)Sq * Sk * Dh * (double)a.nprob, (double)a.nprob * Sq * Dh * 2.0 * 4.0);
+  ProfScope ps(c, PROF_ATTN_FWD, 4.0 * rows * H * (rows / nseq) * Dh, rows * H * Dh * 2.0 * 4.0);
   ps.tag(nseq, Sk, H, 0);
   switch (KT) {
     case 2: launch_fwd<2, 4>(c, a); break;
@@ -335,6 +339,7 @@ struct AttnBwdArgs {
   const float *sq, *sk, *km, *lse;
   int S, H; int64_t nprob;
   bf16_t *dq, *dk, *dv; float *dsq, *dsk;
+  const int32_t* seq_off;  // as AttnArgs::seq_off
 #ifdef SPA3D_ABLATE  // tools/ablate_attn.py builds a separate diagnostic library with this; never defined for libspa3d_hip.so
   int ablate;          // 1: no tile work, 2: no staging (garbage operands), 4: no dq/dk/dv stores
 #endif
@@ -582,9 +587,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
   float* sred = drow + S_pad;     // [2][96] scale-gradient staging
   float* sscale = sred + 2 * DH;  // [2][96] RMSNorm scales (LDS copies: as loop invariants in registers they cost 48 VGPRs)
   char* wt = (char*)(sscale + 2 * DH) + (threadIdx.x >> 6) * WTILE;  // wave-private output tile
-  const int S = g.S, E = g.H * DH;
+  const int E = g.H * DH;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, role = wv >> 2, w = wv & 3, fr = lane & 15, fq = lane >> 4;
-  const int QT = (S + 15) / 16;
   float ds_acc[6][4];  // role 0: d scale_q, role 1: d scale_k
 #pragma unroll
   for (int i = 0; i < 6; ++i)
@@ -597,17 +601,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
   for (int64_t pi = blockIdx.x; pi < g.nprob; pi += gridDim.x) {
     const int64_t prob = map_prob(pi, nseq, g.H);
     const int64_t seq = prob / g.H; const int h = (int)(prob - seq * g.H);
+    const int64_t row0 = g.seq_off ? (int64_t)g.seq_off[seq] : seq * g.S;
+    const int S = g.seq_off ? g.seq_off[seq + 1] - (int)row0 : g.S;
+    const int QT = (S + 15) / 16;
     constexpr int NP = (S_pad + 127) / 128;
     // all five matrices of the problem are requested before the first is used: one memory latency per problem
     RawRows<NP> rq, rk, rv, rd, ro;
 #ifdef SPA3D_ABLATE
     if (!(g.ablate & 2)) {
 #endif
-    rows_load<NP, 128>(rq, g.q + seq * S * g.ldq + h * DH, g.ldq, S);
-    rows_load<NP, 128>(rk, g.k + seq * S * g.ldk + h * DH, g.ldk, S);
-    rows_load<NP, 128>(rv, g.v + seq * S * g.ldv + h * DH, g.ldv, S);
-    rows_load<NP, 128>(rd, g.d_o + seq * S * E + h * DH, E, S);
-    rows_load<NP, 128>(ro, g.o + seq * S * E + h * DH, E, S);
+    rows_load<NP, 128>(rq, g.q + row0 * g.ldq + h * DH, g.ldq, S);
+    rows_load<NP, 128>(rk, g.k + row0 * g.ldk + h * DH, g.ldk, S);
+    rows_load<NP, 128>(rv, g.v + row0 * g.ldv + h * DH, g.ldv, S);
+    rows_load<NP, 128>(rd, g.d_o + row0 * E + h * DH, E, S);
+    rows_load<NP, 128>(ro, g.o + row0 * E + h * DH, E, S);
     __syncthreads();  // previous problem's LDS reads are done
     rows_store<true, NP, 128>(rq, S_pad, sscale, Qs);
     rows_store<true, NP, 128>(rk, S_pad, sscale + DH, Ks);
@@ -620,8 +627,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
       float b = 0.f, m = 0.f, ll = __builtin_inff();  // padding query: P = exp(.. - inf) = 0
       if (t >= S) b = -__builtin_inff();
       else {
-        if (g.km && g.km[seq * S + t] == 0.f) b = NEG_BIG;
-        m = g.lse[(prob * S + t) * 2]; ll = g.lse[(prob * S + t) * 2 + 1];
+        if (g.km && g.km[row0 + t] == 0.f) b = NEG_BIG;
+        m = g.lse[(row0 * g.H + (int64_t)h * S + t) * 2]; ll = g.lse[(row0 * g.H + (int64_t)h * S + t) * 2 + 1];
       }
       kbias[t] = b; mrow[t] = m; lrow[t] = ll;
     }
@@ -637,7 +644,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
         int qrow = q0 + fr; const bool valid = qrow < S; if (!valid) qrow = S - 1;
         u16x4 xraw[6];
         {
-          const bf16_t* xp = g.q + (seq * S + qrow) * g.ldq + h * DH + fq * 4;
+          const bf16_t* xp = g.q + (row0 + qrow) * g.ldq + h * DH + fq * 4;
 #pragma unroll
           for (int dt = 0; dt < 6; ++dt) xraw[dt] = *(const u16x4*)(xp + dt * 16);
         }
@@ -653,7 +660,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
         const int nrows_st = S - q0;
 #endif
         bwd_query_tile<KT>(Ks, Vs, kbias, sscale, qb, dob, mrow[q0 + fr], lrow[q0 + fr], drow[q0 + fr], xraw, valid, wt,
-                           g.dq + (seq * S + q0) * g.ldq + h * DH, g.ldq, nrows_st, ds_acc);
+                           g.dq + (row0 + q0) * g.ldq + h * DH, g.ldq, nrows_st, ds_acc);
       }
     } else {          // ------------------------------------------------------------------ (b) key tiles -> dk, dv
       for (int kt = w; kt < QT; kt += 4) {  // real key tiles only (S_q == S_k)
@@ -661,7 +668,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
         int krow = k0 + fr; const bool valid = krow < S; if (!valid) krow = S - 1;
         u16x4 xraw[6];  // raw k row for the RMSNorm backward, requested before the MFMA work (see part (a))
         {
-          const bf16_t* xp = g.k + (seq * S + krow) * g.ldk + h * DH + fq * 4;
+          const bf16_t* xp = g.k + (row0 + krow) * g.ldk + h * DH + fq * 4;
 #pragma unroll
           for (int dt = 0; dt < 6; ++dt) xraw[dt] = *(const u16x4*)(xp + dt * 16);
         }
@@ -676,8 +683,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
 #else
         const int nrows_st = S - k0;
 #endif
-        bwd_key_tile<KT>(Qs, dOs, mrow, lrow, drow, sscale + DH, kb, vb, kbias[k0 + fr], xraw, valid, wt, g.dk + (seq * S + k0) * g.ldk + h * DH,
-                         g.ldk, g.dv + (seq * S + k0) * g.ldv + h * DH, g.ldv, nrows_st, ds_acc);
+        bwd_key_tile<KT>(Qs, dOs, mrow, lrow, drow, sscale + DH, kb, vb, kbias[k0 + fr], xraw, valid, wt, g.dk + (row0 + k0) * g.ldk + h * DH,
+                         g.ldk, g.dv + (row0 + k0) * g.ldv + h * DH, g.ldv, nrows_st, ds_acc);
       }
     }
   }
@@ -693,9 +700,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_split_kernel(AttnBwdArgs 
   float* kbias = (float*)(B1 + S_pad * ROWB); float* mrow = kbias + S_pad; float* lrow = mrow + S_pad; float* drow = lrow + S_pad;
   float* sred = drow + S_pad; float* sscale = sred + 2 * DH;
   char* wtile = (char*)(sscale + 2 * DH);  // wave-private tiles: own-row staging in pass A, output rows in both passes
-  const int S = g.S, E = g.H * DH;
+  const int E = g.H * DH;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fq = lane >> 4;
-  const int QT = (S + 15) / 16;
   float dsq_acc[6][4], dsk_acc[6][4];
 #pragma unroll
   for (int i = 0; i < 6; ++i)
@@ -707,18 +713,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_split_kernel(AttnBwdArgs 
   for (int64_t pi = blockIdx.x; pi < g.nprob; pi += gridDim.x) {
     const int64_t prob = map_prob(pi, nseq, g.H);
     const int64_t seq = prob / g.H; const int h = (int)(prob - seq * g.H);
+    const int64_t row0 = g.seq_off ? (int64_t)g.seq_off[seq] : seq * g.S;
+    const int S = g.seq_off ? g.seq_off[seq + 1] - (int)row0 : g.S;
+    const int QT = (S + 15) / 16;
     // ================================================================== pass A: K^, V resident; query tiles -> dq
     {
       RawRows<NP> rk, rv;
-      rows_load<NP, RPP>(rk, g.k + seq * S * g.ldk + h * DH, g.ldk, S);
-      rows_load<NP, RPP>(rv, g.v + seq * S * g.ldv + h * DH, g.ldv, S);
+      rows_load<NP, RPP>(rk, g.k + row0 * g.ldk + h * DH, g.ldk, S);
+      rows_load<NP, RPP>(rv, g.v + row0 * g.ldv + h * DH, g.ldv, S);
       __syncthreads();  // previous problem's pass-B reads are done
       rows_store<true, NP, RPP>(rk, S_pad, sscale + DH, B0);
       rows_store<false, NP, RPP>(rv, S_pad, nullptr, B1);
       for (int t = tid; t < S_pad; t += NTH) {
         float b = 0.f;
         if (t >= S) b = -__builtin_inff();
-        else if (g.km && g.km[seq * S + t] == 0.f) b = NEG_BIG;
+        else if (g.km && g.km[row0 + t] == 0.f) b = NEG_BIG;
         kbias[t] = b;
       }
       __syncthreads();
@@ -730,7 +739,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_split_kernel(AttnBwdArgs 
       // rows are loaded coalesced (4 lanes per row), normalised exactly as the staged images are, and read back as B-operand
       // fragments.  (Fragment-shaped global loads + in-register normalisation cost ~390 spilled VGPRs here.)
       const int tr = lane >> 2, part = lane & 3;
-      const int64_t grow = seq * S + (q0 + tr < S ? q0 + tr : S - 1);
+      const int64_t grow = row0 + (q0 + tr < S ? q0 + tr : S - 1);
       u16x8 xq[3], xd[3], xo[3]; u16x4 xraw[6];
       {
         const u16x8* pq = (const u16x8*)(g.q + grow * g.ldq + h * DH) + part;
@@ -738,12 +747,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_split_kernel(AttnBwdArgs 
         const u16x8* po = (const u16x8*)(g.o + grow * E + h * DH) + part;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { xq[c] = pq[4 * c]; xd[c] = pd[4 * c]; xo[c] = po[4 * c]; }
-        const bf16_t* xp = g.q + (seq * S + qrow) * g.ldq + h * DH + fq * 4;
+        const bf16_t* xp = g.q + (row0 + qrow) * g.ldq + h * DH + fq * 4;
 #pragma unroll
         for (int dt = 0; dt < 6; ++dt) xraw[dt] = *(const u16x4*)(xp + dt * 16);
       }
       float mq = 0.f, lq = __builtin_inff();  // padding query: P = exp(.. - inf) = 0
-      if (valid) { mq = g.lse[(prob * S + qrow) * 2]; lq = g.lse[(prob * S + qrow) * 2 + 1]; }
+      if (valid) { mq = g.lse[(row0 * g.H + (int64_t)h * S + qrow) * 2]; lq = g.lse[(row0 * g.H + (int64_t)h * S + qrow) * 2 + 1]; }
       char* wt = wtile + w * WTILE; float* wdel = (float*)(wt + 16 * WROW);
       mfma16x8 qb[3], dob[3];
       {  // q^ rows -> tile -> fragments
@@ -781,21 +790,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_split_kernel(AttnBwdArgs 
         dsum = wdel[fr];
         asm volatile("" ::: "memory");
       }
-      bwd_query_tile<KT>(B0, B1, kbias, sscale, qb, dob, mq, lq, dsum, xraw, valid, wt, g.dq + (seq * S + q0) * g.ldq + h * DH, g.ldq, S - q0,
+      bwd_query_tile<KT>(B0, B1, kbias, sscale, qb, dob, mq, lq, dsum, xraw, valid, wt, g.dq + (row0 + q0) * g.ldq + h * DH, g.ldq, S - q0,
                          dsq_acc);
     }
     // ================================================================== pass B: Q^, dO resident; key tiles -> dk, dv
     {
       RawRows<NP> rq, rd, ro;
-      rows_load<NP, RPP>(rq, g.q + seq * S * g.ldq + h * DH, g.ldq, S);
-      rows_load<NP, RPP>(rd, g.d_o + seq * S * E + h * DH, E, S);
-      rows_load<NP, RPP>(ro, g.o + seq * S * E + h * DH, E, S);
+      rows_load<NP, RPP>(rq, g.q + row0 * g.ldq + h * DH, g.ldq, S);
+      rows_load<NP, RPP>(rd, g.d_o + row0 * E + h * DH, E, S);
+      rows_load<NP, RPP>(ro, g.o + row0 * E + h * DH, E, S);
       __syncthreads();  // pass A's reads of K^, V are done
       rows_store<true, NP, RPP>(rq, S_pad, sscale, B0);
       store_do_delta<NP, RPP>(rd, ro, S_pad, B1, drow);
       for (int t = tid; t < S_pad; t += NTH) {
         float m = 0.f, ll = __builtin_inff();
-        if (t < S) { m = g.lse[(prob * S + t) * 2]; ll = g.lse[(prob * S + t) * 2 + 1]; }
+        if (t < S) { m = g.lse[(row0 * g.H + (int64_t)h * S + t) * 2]; ll = g.lse[(row0 * g.H + (int64_t)h * S + t) * 2 + 1]; }
         mrow[t] = m; lrow[t] = ll;
       }
       __syncthreads();
@@ -803,8 +812,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_split_kernel(AttnBwdArgs 
     for (int kt = w; kt < QT; kt += NW) {
       const int k0 = kt * 16;
       int krow = k0 + fr; const bool valid = krow < S; if (!valid) krow = S - 1;
-      const bf16_t* kp = g.k + (seq * S + krow) * g.ldk + h * DH;
-      const bf16_t* vp = g.v + (seq * S + krow) * g.ldv + h * DH + fq * 8;
+      const bf16_t* kp = g.k + (row0 + krow) * g.ldk + h * DH;
+      const bf16_t* vp = g.v + (row0 + krow) * g.ldv + h * DH + fq * 8;
       u16x8 kx[3], vx[3]; u16x4 xraw[6];
 #pragma unroll
       for (int s = 0; s < 3; ++s) { kx[s] = *(const u16x8*)(kp + fq * 8 + s * 32); vx[s] = *(const u16x8*)(vp + s * 32); }
@@ -815,8 +824,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_split_kernel(AttnBwdArgs 
 #pragma unroll
       for (int s = 0; s < 3; ++s) vb[s] = __builtin_bit_cast(mfma16x8, vx[s]);
       const float kbv = kbias[k0 + fr];  // written in pass A, untouched since
-      bwd_key_tile<KT>(B0, B1, mrow, lrow, drow, sscale + DH, kb, vb, kbv, xraw, valid, wtile + w * WTILE, g.dk + (seq * S + k0) * g.ldk + h * DH,
-                       g.ldk, g.dv + (seq * S + k0) * g.ldv + h * DH, g.ldv, S - k0, dsk_acc);
+      bwd_key_tile<KT>(B0, B1, mrow, lrow, drow, sscale + DH, kb, vb, kbv, xraw, valid, wtile + w * WTILE, g.dk + (row0 + k0) * g.ldk + h * DH,
+                       g.ldk, g.dv + (row0 + k0) * g.ldv + h * DH, g.ldv, S - k0, dsk_acc);
     }
   }
   flush_scale_grads<NTH>(g, sred, dsq_acc, dsk_acc, true, true);
@@ -850,19 +859,21 @@ static void launch_bwd(spa3d_ctx* c, const AttnBwdArgs& a) {
 
 bool attn_fused_bwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ldq, int64_t ldk, int64_t ldv,
                          const float* sq, const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, const bf16_t* o,
-                         const float* lse, const bf16_t* d_o, bf16_t* dq, bf16_t* dk, bf16_t* dv, float* dsq, float* dsk) {
+                         const float* lse, const bf16_t* d_o, bf16_t* dq, bf16_t* dk, bf16_t* dv, float* dsq, float* dsk,
+                         const int32_t* seq_off, int64_t total_rows) {
   if (Dh != DH || Sq != Sk || Sk < 2 || Sk > ATTN_MAX_S || !o || !lse) return false;
   if (ldq % 8 || ldk % 8 || ldv % 8 || !al16(q) || !al16(k) || !al16(v) || !al16(o) || !al16(d_o) || !al16(dq) || !al16(dk) || !al16(dv) ||
       !al16(sq) || !al16(sk))
     return false;
   if (c->dry) return true;
   AttnBwdArgs a; a.q = q; a.k = k; a.v = v; a.o = o; a.d_o = d_o; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.sq = sq; a.sk = sk; a.km = km;
-  a.lse = lse; a.S = Sk; a.H = H; a.nprob = nseq * H; a.dq = dq; a.dk = dk; a.dv = dv; a.dsq = dsq; a.dsk = dsk;
+  a.lse = lse; a.S = Sk; a.H = H; a.nprob = nseq * H; a.dq = dq; a.dk = dk; a.dv = dv; a.dsq = dsq; a.dsk = dsk; a.seq_off = seq_off;
+  const double rows = total_rows > 0 ? (double)total_rows : (double)nseq * Sk;
 #ifdef SPA3D_ABLATE
   { const char* e = getenv("SPA3D_ABLATE"); a.ablate = e ? atoi(e) : 0; }
 #endif
   const int KT = ((Sk + 31) / 32) * 2;
-  ProfScope ps(c, PROF_ATTN_BWD, 14.0 * (double)Sq * Sk * Dh * (double)a.nprob, (double)a.nprob * Sq * Dh * 2.0 * 8.0);
+  ProfScope ps(c, PROF_ATTN_BWD, 14.0 * rows * H * (rows / nseq) * Dh, rows * H * Dh * 2.0 * 8.0);
   ps.tag(nseq, Sk, H, 0);
   switch (KT) {
     case 2: launch_bwd<2>(c, a); break;

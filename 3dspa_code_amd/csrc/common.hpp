@@ -144,6 +144,7 @@ struct spa3d_ctx {
   int hip_err = 0;
   int gemm_impl = 0;  // 0 auto, 1 generic only
   int attn_impl = 0;
+  int prune = 1;          // drop masked frame tokens from the track encoder (3DSPA model, fused 16-bit attention path); SPA3D_PRUNE=0 disables
   float loss_scale = 1.f;  // the 16-bit backward runs at loss x scale, parameter gradients are scaled back at the end: 1 = off (bf16 / fp32),
                            // > 0 a fixed scale, < 0 automatic with |loss_scale| the target head-gradient magnitude (fp16 mode: -16)
   int attn_bwd_mode = 0;  // fused attention backward structure: 0 auto, 1 four images + concurrent roles, 2 split-pass 4 waves (2 WG/CU), 3 split-pass 8 waves
@@ -245,6 +246,9 @@ template <typename T> void k_transpose(spa3d_ctx*, const T* src, int rows, int c
 template <typename T> void k_set_readout_rows(spa3d_ctx*, T* tok, const float* readout, int64_t nseq, int S, int d);
 void k_keymask(spa3d_ctx*, const float* visible, const int32_t* boundary, int64_t nseq, int N, int T_, float* km);
 template <typename T> void k_gather_rows(spa3d_ctx*, const T* src, int64_t src_stride_rows, T* dst, int64_t n, int d);
+// token pruning of the track encoder (kernels.hip): plan (returns the kept-row count, one stream sync) and rows-by-index movers
+int64_t k_prune_plan(spa3d_ctx*, const float* km, int64_t nseq, int S, int32_t* cnt, int32_t* seq_off, int32_t* row_src);
+template <typename T> void k_rows_idx(spa3d_ctx*, int mode /*0 gather, 1 scatter, 2 scatter-add*/, const T* src, const int32_t* idx, T* dst, int64_t n, int d);
 template <typename T> void k_scatter_rows(spa3d_ctx*, const T* src, T* dst, int64_t dst_stride_rows, int64_t n, int d);
 template <typename T> void k_compact_tokens(spa3d_ctx*, const T* tok, T* dst, int64_t nseq, int S, int d);
 template <typename T> void k_broadcast_rows(spa3d_ctx*, const float* src, int rows, int d, T* dst, int64_t B);
@@ -276,10 +280,11 @@ void k_uniform_noise(spa3d_ctx*, float* out, int64_t n, uint32_t k0, uint32_t k1
 // single-query attention of the pruned last block (kernels.hip)
 template <typename T> void k_attn_q1_fwd(spa3d_ctx*, const T* q0, int64_t ldq0, const T* k, const T* v, int64_t ldk, int64_t ldv,
                                          const float* sq, const float* sk, const float* km, int64_t nseq, int S, int H, int Dh, T* o0,
-                                         float* p0);
+                                         float* p0, const int32_t* seq_off = nullptr);
 template <typename T> void k_attn_q1_bwd(spa3d_ctx*, const T* q0, int64_t ldq0, const T* k, const T* v, int64_t ldk, int64_t ldv,
                                          const float* sq, const float* sk, const float* km, int64_t nseq, int S, int H, int Dh,
-                                         const float* p0, const T* d_o0, T* dq0, T* dk, T* dv, float* dsq, float* dsk);
+                                         const float* p0, const T* d_o0, T* dq0, T* dk, T* dv, float* dsq, float* dsk,
+                                         const int32_t* seq_off = nullptr);
 template <typename T> void k_add_rows_strided(spa3d_ctx*, T* dst, const T* src, int64_t dst_stride_rows, int64_t n, int d);
 // 2-D TRAJAN twin (track_autoencoder.py:117-390)
 template <typename T> void k_vis_mean_pool(spa3d_ctx*, const T* tok, const float* vis, int64_t nseq, int T_, int d, T* out);

@@ -770,6 +770,103 @@ template <typename T> void k_scatter_rows(spa3d_ctx* c, const T* src, T* dst, in
   if (c->dry || n == 0) return;
   scatter_rows_kernel<T><<<GRID1D(n * d, 256), 256, 0, c->stream>>>(src, dst, drows, n, d); SPA_LAUNCH_CHECK(c);
 }
+// ---------------------------------------------------------------------------------------------
+// Token pruning of the track encoder (3DSPA model, 16-bit fused path).  A frame token whose key is masked (occluded, or at / past
+// boundary_frame: track_autoencoder_3d.py:167-184) is never attended to, and only token 0 leaves the encoder (:187-188), so a masked
+// token's own row influences nothing: the stack runs on COMPACTED, ragged sequences (token 0 + the visible frames, in time order).
+//   seq_off [nseq + 1]  first compact row of every sequence (exclusive scan of the kept counts; seq_off[nseq] = kept rows in all)
+//   row_src [kept]      dense row (seq * S + t) behind every compact row
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prune_count_kernel(const float* __restrict__ km, int64_t nseq, int S, int32_t* __restrict__ cnt) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t seq = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); seq < nseq; seq += (int64_t)gridDim.x * 4) {
+    int n = 0;
+    for (int t = lane; t < S; t += 64) n += km[seq * S + t] != 0.f ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if (lane == 0) cnt[seq] = n;
+  }
+}
+// exclusive scan of cnt[0..n) into off[0..n] by ONE workgroup (n <= a few hundred thousand sequences): per-thread chunk sums, a block
+// scan of the 1024 partials, then the chunk is re-walked.  off may alias cnt only if they are the same buffer shifted: they are not.
+__global__ __launch_bounds__(1024) void prune_scan_kernel(const int32_t* __restrict__ cnt, int64_t n, int32_t* __restrict__ off) {
+  __shared__ int32_t part[1024];
+  const int tid = threadIdx.x;
+  const int64_t per = (n + 1023) / 1024, a = tid * per, b = a + per < n ? a + per : n;
+  int32_t s = 0;
+  for (int64_t i = a; i < b; ++i) s += cnt[i];
+  part[tid] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int32_t v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int32_t run = tid ? part[tid - 1] : 0;
+  for (int64_t i = a; i < b; ++i) { off[i] = run; run += cnt[i]; }
+  if (tid == 1023) off[n] = part[1023];
+}
+__global__ __launch_bounds__(256) void prune_fill_kernel(const float* __restrict__ km, int64_t nseq, int S, const int32_t* __restrict__ off,
+                                                         int32_t* __restrict__ row_src) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t seq = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); seq < nseq; seq += (int64_t)gridDim.x * 4) {
+    int base = off[seq];
+    for (int t0 = 0; t0 < S; t0 += 64) {
+      const int t = t0 + lane;
+      const bool keep = t < S && km[seq * S + t] != 0.f;
+      const unsigned long long m = __ballot(keep);
+      if (keep) row_src[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)(seq * S + t);
+      base += __popcll(m);
+    }
+  }
+}
+// returns the number of kept rows (ONE stream synchronisation: the row count sizes every launch that follows); dense count when dry
+int64_t k_prune_plan(spa3d_ctx* c, const float* km, int64_t nseq, int S, int32_t* cnt, int32_t* seq_off, int32_t* row_src) {
+  if (c->dry) return nseq * S;
+  prune_count_kernel<<<(unsigned)std::min<int64_t>(cdiv(nseq, 4), 8192), 256, 0, c->stream>>>(km, nseq, S, cnt); SPA_LAUNCH_CHECK(c);
+  prune_scan_kernel<<<1, 1024, 0, c->stream>>>(cnt, nseq, seq_off); SPA_LAUNCH_CHECK(c);
+  prune_fill_kernel<<<(unsigned)std::min<int64_t>(cdiv(nseq, 4), 8192), 256, 0, c->stream>>>(km, nseq, S, seq_off, row_src); SPA_LAUNCH_CHECK(c);
+  int32_t kept = 0;
+  if (hipMemcpyAsync(&kept, seq_off + nseq, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess) {
+    if (!c->hip_err) { c->hip_err = -4; c->err = "prune plan: reading the kept-row count failed"; }
+    return nseq * S;
+  }
+  return kept;
+}
+// rows by index, 16 bytes per thread: MODE 0 dst[i] = src[idx[i]] (gather), 1 dst[idx[i]] = src[i] (scatter), 2 dst[idx[i]] += src[i]
+template <typename T, int MODE>
+__global__ void rows_idx_kernel(const T* __restrict__ src, const int32_t* __restrict__ idx, T* __restrict__ dst, int64_t n, int d) {
+  constexpr int NV = VecOf<T>::N;
+  const int cpr = d / NV;  // 16-byte chunks per row (host: d % NV == 0)
+  const int64_t tot = n * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cpr; const int ch = (int)(i - r * cpr);
+    const int64_t other = idx[r];
+    const int64_t so = (MODE == 0 ? other : r) * d + ch * NV, dofs = (MODE == 0 ? r : other) * d + ch * NV;
+    if constexpr (MODE == 2) {
+      float a[NV], b[NV];
+      load_vec<T, NV>(src + so, a); load_vec<T, NV>(dst + dofs, b);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) b[j] += a[j];
+      store_vec<T, NV>(dst + dofs, b);
+    } else {
+      *(uint4*)(dst + dofs) = *(const uint4*)(src + so);
+    }
+  }
+}
+template <typename T> void k_rows_idx(spa3d_ctx* c, int mode, const T* src, const int32_t* idx, T* dst, int64_t n, int d) {
+  if (c->dry || n == 0) return;
+  constexpr int NV = VecOf<T>::N;
+  if (d % NV) { if (!c->hip_err) { c->hip_err = -5; c->err = "rows_idx: row width must be a multiple of 16 bytes"; } return; }
+  const dim3 g = GRID1D(n * (d / NV), 256);
+  if (mode == 0) rows_idx_kernel<T, 0><<<g, 256, 0, c->stream>>>(src, idx, dst, n, d);
+  else if (mode == 1) rows_idx_kernel<T, 1><<<g, 256, 0, c->stream>>>(src, idx, dst, n, d);
+  else rows_idx_kernel<T, 2><<<g, 256, 0, c->stream>>>(src, idx, dst, n, d);
+  SPA_LAUNCH_CHECK(c);
+}
+
 // copy rows 1..S-1 of each sequence into a compact [nseq*(S-1)][d] buffer (drop the readout row)
 template <typename T>
 __global__ void compact_tokens_kernel(const T* __restrict__ tok, T* __restrict__ dst, int64_t nseq, int S, int d) {
@@ -1329,6 +1426,7 @@ void k_uniform_noise(spa3d_ctx* c, float* out, int64_t n, uint32_t k0, uint32_t 
   template void k_transpose<T>(spa3d_ctx*, const T*, int, int, T*);                                                                    \
   template void k_set_readout_rows<T>(spa3d_ctx*, T*, const float*, int64_t, int, int);                                                \
   template void k_gather_rows<T>(spa3d_ctx*, const T*, int64_t, T*, int64_t, int);                                                     \
+  template void k_rows_idx<T>(spa3d_ctx*, int, const T*, const int32_t*, T*, int64_t, int);                                                     \
   template void k_scatter_rows<T>(spa3d_ctx*, const T*, T*, int64_t, int64_t, int);                                                    \
   template void k_compact_tokens<T>(spa3d_ctx*, const T*, T*, int64_t, int, int);                                                      \
   template void k_broadcast_rows<T>(spa3d_ctx*, const float*, int, int, T*, int64_t);                                                  \
@@ -1398,20 +1496,23 @@ __device__ __forceinline__ float kgrp_sum(float v) {
 template <typename T, int CC>
 __global__ __launch_bounds__(256) void attn_q1_fwd_kernel(const T* __restrict__ q0, int64_t ldq0, const T* __restrict__ k, const T* __restrict__ v,
                                                           int64_t ldk, int64_t ldv, const float* __restrict__ sq, const float* __restrict__ sk,
-                                                          const float* __restrict__ km, int64_t nprob, int S, int H, T* __restrict__ o0,
-                                                          float* __restrict__ p0, int vec_) {
+                                                          const float* __restrict__ km, int64_t nprob, int Smax, int H, T* __restrict__ o0,
+                                                          float* __restrict__ p0, int vec_, const int32_t* __restrict__ seq_off) {
   __shared__ float scs[4][Q1_MAXS];
   constexpr int Dh = CC * 4;
   const int lane = threadIdx.x & 63, part = lane & 3, kg = lane >> 2, wv = threadIdx.x >> 6;
   const bool vec = vec_ != 0;
   float* sc = scs[wv];
   const float alpha = rsqrtf((float)Dh);
-  const int nit = (S + 15) / 16;
   float sqv[CC], skv[CC];
 #pragma unroll
   for (int j = 0; j < CC; ++j) { const int ch = q1_chan<T, CC>(j, part, vec); sqv[j] = sq[ch]; skv[j] = sk[ch]; }
   for (int64_t prob = (int64_t)blockIdx.x * 4 + wv; prob < nprob; prob += (int64_t)gridDim.x * 4) {
     const int64_t seq = prob / H; const int h = (int)(prob - seq * H);
+    // ragged sequences (token pruning): rows [seq_off[seq], seq_off[seq+1]) of the compact tensors; dense otherwise
+    const int64_t rowbase = seq_off ? (int64_t)seq_off[seq] : seq * Smax;
+    const int S = seq_off ? seq_off[seq + 1] - (int)rowbase : Smax;
+    const int nit = (S + 15) / 16;
     float qh[CC];
     q1_load<T, CC>(q0 + seq * ldq0 + h * Dh, vec, qh, part);
     float ss = 0.f;
@@ -1426,13 +1527,13 @@ __global__ __launch_bounds__(256) void attn_q1_fwd_kernel(const T* __restrict__ 
       const int key = it * 16 + kg;
       const int kr_ = key < S ? key : S - 1;  // absent keys re-read the last row (keeps the quad shuffles convergent), result unused
       float kv_[CC];
-      q1_load<T, CC>(k + (seq * S + kr_) * ldk + h * Dh, vec, kv_, part);
+      q1_load<T, CC>(k + (rowbase + kr_) * ldk + h * Dh, vec, kv_, part);
       float ks = 0.f, d = 0.f;
 #pragma unroll
       for (int j = 0; j < CC; ++j) { ks += kv_[j] * kv_[j]; d += qh[j] * kv_[j] * skv[j]; }
       ks = quad_sum(ks); d = quad_sum(d);
       float lg = d * rsqrtf(ks / Dh + 1e-6f) * alpha;
-      if (km && km[seq * S + kr_] == 0.f) lg = -3.4028234663852886e38f;
+      if (km && km[rowbase + kr_] == 0.f) lg = -3.4028234663852886e38f;
       if (key < S) { m = fmaxf(m, lg); if (part == 0) sc[key] = lg; }
     }
 #pragma unroll
@@ -1449,9 +1550,9 @@ __global__ __launch_bounds__(256) void attn_q1_fwd_kernel(const T* __restrict__ 
       const int key = it * 16 + kg;
       if (key < S) {
         const float p = sc[key] * inv;
-        if (part == 0) p0[prob * S + key] = p;
+        if (part == 0) p0[prob * Smax + key] = p;
         float vv[CC];
-        q1_load<T, CC>(v + (seq * S + key) * ldv + h * Dh, vec, vv, part);
+        q1_load<T, CC>(v + (rowbase + key) * ldv + h * Dh, vec, vv, part);
 #pragma unroll
         for (int j = 0; j < CC; ++j) acc[j] += p * vv[j];
       }
@@ -1463,7 +1564,7 @@ __global__ __launch_bounds__(256) void attn_q1_fwd_kernel(const T* __restrict__ 
 }
 template <typename T>
 void k_attn_q1_fwd(spa3d_ctx* c, const T* q0, int64_t ldq0, const T* k, const T* v, int64_t ldk, int64_t ldv, const float* sq, const float* sk,
-                   const float* km, int64_t nseq, int S, int H, int Dh, T* o0, float* p0) {
+                   const float* km, int64_t nseq, int S, int H, int Dh, T* o0, float* p0, const int32_t* seq_off) {
   if (c->dry || nseq == 0) return;
   if (S > Q1_MAXS || Dh % 4 || Dh > 128) { if (!c->hip_err) { c->hip_err = -3; c->err = "attn_q1: S <= 320 and Dh % 4 == 0, Dh <= 128 required"; } return; }
   const int64_t nprob = nseq * H;
@@ -1473,7 +1574,7 @@ void k_attn_q1_fwd(spa3d_ctx* c, const T* q0, int64_t ldq0, const T* k, const T*
   constexpr int NV = VecOf<T>::N;
   const int vec = (Dh % (4 * NV) == 0 && ldk % NV == 0 && ldv % NV == 0 && ldq0 % NV == 0 &&
                    ((((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)q0) | ((uintptr_t)o0)) & 15) == 0) ? 1 : 0;
-#define Q1F(CCv) attn_q1_fwd_kernel<T, CCv><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, o0, p0, vec)
+#define Q1F(CCv) attn_q1_fwd_kernel<T, CCv><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, o0, p0, vec, seq_off)
   switch (Dh / 4) { case 24: Q1F(24); break; case 16: Q1F(16); break; case 32: Q1F(32); break; case 8: Q1F(8); break; case 4: Q1F(4); break;
     case 2: Q1F(2); break; default: if (!c->hip_err) { c->hip_err = -3; c->err = "attn_q1: unsupported head width"; } return; }
 #undef Q1F
@@ -1487,10 +1588,10 @@ void k_attn_q1_fwd(spa3d_ctx* c, const T* q0, int64_t ldq0, const T* k, const T*
 template <typename T, int CC>
 __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ q0, int64_t ldq0, const T* __restrict__ k, const T* __restrict__ v,
                                                           int64_t ldk, int64_t ldv, const float* __restrict__ sq, const float* __restrict__ sk,
-                                                          const float* __restrict__ km, int64_t nprob, int S, int H,
+                                                          const float* __restrict__ km, int64_t nprob, int Smax, int H,
                                                           const float* __restrict__ p0, const T* __restrict__ d_o0, T* __restrict__ dq0,
                                                           T* __restrict__ dk, T* __restrict__ dv, float* __restrict__ dsq, float* __restrict__ dsk,
-                                                          int vec_) {
+                                                          int vec_, const int32_t* __restrict__ seq_off) {
   __shared__ float dps[4][Q1_MAXS];
   __shared__ float scl[2][4 * CC];  // s_q, s_k in lane-channel order [part][j]
   __shared__ float red[2][4 * CC];  // block accumulators of d s_q, d s_k
@@ -1503,7 +1604,6 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
   const float* sql = scl[0] + part * CC;
   const float* skl = scl[1] + part * CC;
   const float alpha = rsqrtf((float)Dh);
-  const int nit = (S + 15) / 16;
   for (int t = threadIdx.x; t < 4 * CC; t += 256) {
     const int pt = t / CC, j = t - pt * CC;
     const int ch = q1_chan<T, CC>(j, pt, vec);
@@ -1512,6 +1612,10 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
   __syncthreads();
   for (int64_t prob = (int64_t)blockIdx.x * 4 + wv; prob < nprob; prob += (int64_t)gridDim.x * 4) {
     const int64_t seq = prob / H; const int h = (int)(prob - seq * H);
+    // ragged sequences (token pruning): rows [seq_off[seq], seq_off[seq+1]) of the compact tensors; dense otherwise
+    const int64_t rowbase = seq_off ? (int64_t)seq_off[seq] : seq * Smax;
+    const int S = seq_off ? seq_off[seq + 1] - (int)rowbase : Smax;
+    const int nit = (S + 15) / 16;
     float qs[CC], dout[CC];
     q1_load<T, CC>(q0 + seq * ldq0 + h * Dh, vec, qs, part);
     q1_load<T, CC>(d_o0 + seq * (int64_t)H * Dh + h * Dh, vec, dout, part);
@@ -1528,12 +1632,12 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
       const int key = it * 16 + kg;
       const int kr_ = key < S ? key : S - 1;
       float vv[CC];
-      q1_load<T, CC>(v + (seq * S + kr_) * ldv + h * Dh, vec, vv, part);
+      q1_load<T, CC>(v + (rowbase + kr_) * ldv + h * Dh, vec, vv, part);
       float d = 0.f;
 #pragma unroll
       for (int j = 0; j < CC; ++j) d += dout[j] * vv[j];
       d = quad_sum(d);
-      if (key < S && part == 0) { dp[key] = d; pd += p0[prob * S + key] * d; }
+      if (key < S && part == 0) { dp[key] = d; pd += p0[prob * Smax + key] * d; }
     }
     pd = wave_sum(pd);
     // pass 2: per key dv, dk (through the RMSNorm) and u
@@ -1544,15 +1648,15 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
       const int key = it * 16 + kg;
       const bool valid = key < S;
       const int kr_ = valid ? key : S - 1;
-      const int64_t roff = seq * S + kr_;
+      const int64_t roff = rowbase + kr_;
       float xk[CC];
       q1_load<T, CC>(k + roff * ldk + h * Dh, vec, xk, part);
       float ks = 0.f;
 #pragma unroll
       for (int j = 0; j < CC; ++j) ks += xk[j] * xk[j];
       const float rk = rsqrtf(quad_sum(ks) / Dh + 1e-6f);
-      const float p = valid ? p0[prob * S + kr_] : 0.f;
-      const bool keep = !(km && km[seq * S + kr_] == 0.f);
+      const float p = valid ? p0[prob * Smax + kr_] : 0.f;
+      const bool keep = !(km && km[rowbase + kr_] == 0.f);
       const float ds = (valid && keep) ? p * (dp[kr_] - pd) * alpha : 0.f;  // where() passes no gradient to masked logits
       float gx = 0.f;
 #pragma unroll
@@ -1617,7 +1721,7 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
 template <typename T>
 void k_attn_q1_bwd(spa3d_ctx* c, const T* q0, int64_t ldq0, const T* k, const T* v, int64_t ldk, int64_t ldv, const float* sq, const float* sk,
                    const float* km, int64_t nseq, int S, int H, int Dh, const float* p0, const T* d_o0, T* dq0, T* dk, T* dv, float* dsq,
-                   float* dsk) {
+                   float* dsk, const int32_t* seq_off) {
   if (c->dry || nseq == 0) return;
   if (S > Q1_MAXS || Dh % 4 || Dh > 128) { if (!c->hip_err) { c->hip_err = -3; c->err = "attn_q1: S <= 320 and Dh % 4 == 0, Dh <= 128 required"; } return; }
   const int64_t nprob = nseq * H;
@@ -1628,7 +1732,7 @@ void k_attn_q1_bwd(spa3d_ctx* c, const T* q0, int64_t ldq0, const T* k, const T*
   const int vec = (Dh % (4 * NV) == 0 && ldk % NV == 0 && ldv % NV == 0 && ldq0 % NV == 0 &&
                    ((((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)dk) | ((uintptr_t)dv) | ((uintptr_t)q0) | ((uintptr_t)d_o0) |
                      ((uintptr_t)dq0)) & 15) == 0) ? 1 : 0;
-#define Q1B(CCv) attn_q1_bwd_kernel<T, CCv><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, p0, d_o0, dq0, dk, dv, dsq, dsk, vec)
+#define Q1B(CCv) attn_q1_bwd_kernel<T, CCv><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, p0, d_o0, dq0, dk, dv, dsq, dsk, vec, seq_off)
   switch (Dh / 4) { case 24: Q1B(24); break; case 16: Q1B(16); break; case 32: Q1B(32); break; case 8: Q1B(8); break; case 4: Q1B(4); break;
     case 2: Q1B(2); break; default: if (!c->hip_err) { c->hip_err = -3; c->err = "attn_q1: unsupported head width"; } return; }
 #undef Q1B
@@ -1650,9 +1754,9 @@ template <typename T> void k_add_rows_strided(spa3d_ctx* c, T* dst, const T* src
 }
 #define INST_Q1(T)                                                                                                                     \
   template void k_attn_q1_fwd<T>(spa3d_ctx*, const T*, int64_t, const T*, const T*, int64_t, int64_t, const float*, const float*,       \
-                                 const float*, int64_t, int, int, int, T*, float*);                                                     \
+                                 const float*, int64_t, int, int, int, T*, float*, const int32_t*);                                     \
   template void k_attn_q1_bwd<T>(spa3d_ctx*, const T*, int64_t, const T*, const T*, int64_t, int64_t, const float*, const float*,       \
-                                 const float*, int64_t, int, int, int, const float*, const T*, T*, T*, T*, float*, float*);             \
+                                 const float*, int64_t, int, int, int, const float*, const T*, T*, T*, T*, float*, float*, const int32_t*); \
   template void k_add_rows_strided<T>(spa3d_ctx*, T*, const T*, int64_t, int64_t, int);
 INST_Q1(float)
 INST_Q1(bf16_t)

@@ -24,11 +24,12 @@ struct RunArgs {
 namespace SPA_NS {
 template <typename T>
 void attention_fwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq,
-                   const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, T* o, float* lse, int impl);
+                   const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, T* o, float* lse, int impl,
+                   const int32_t* seq_off = nullptr, int64_t total_rows = 0);
 template <typename T>
 void attention_bwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq,
                    const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, const T* o, const float* lse, const T* d_o,
-                   T* dq, T* dk, T* dv, float* dsq, float* dsk, int impl);
+                   T* dq, T* dk, T* dv, float* dsq, float* dsk, int impl, const int32_t* seq_off = nullptr, int64_t total_rows = 0);
 
 static const float L1_WEIGHT = 5000.0f, BCE_WEIGHT = 1e-8f;  // train.py:96
 
@@ -56,6 +57,11 @@ template <typename T> struct BlockStash {
   T *x, *nq, *qkv, *o, *a, *na, *hpre, *h, *cq = nullptr, *ckv = nullptr, *co = nullptr;
   float *st1, *st2, *lse = nullptr, *clse = nullptr;
 };
+
+// Ragged (token-pruned) sequences of the track encoder: compact row offsets [nseq + 1] and the exact kept-row count; off == nullptr: dense.
+// NT GEMMs run on the row count rounded up to 8 (the persistent kernels want M % 8 == 0; rows are independent there and every compact
+// buffer carries the slack); reductions over rows (dW, LayerNorm, attention) use the exact count.
+struct Rag { const int32_t* off = nullptr; int64_t rows = 0; };
 
 template <typename T> struct Net {
   spa3d_ctx* c; const spa3d_config& g; const float* P; float* G;
@@ -186,27 +192,28 @@ template <typename T> struct Net {
 
   // ------------------------------------------------------------------ attention core (attention.hip)
   void attn_fwd(const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq, const float* sk,
-                const float* km, int64_t nseq, int Sq, int Sk, T* o, float* lse) {
-    attention_fwd<T>(c, q, k, v, ldq, ldk, ldv, sq, sk, km, nseq, Sq, Sk, H, Dh, o, lse, c->attn_impl);
+                const float* km, int64_t nseq, int Sq, int Sk, T* o, float* lse, const Rag& rg = Rag()) {
+    attention_fwd<T>(c, q, k, v, ldq, ldk, ldv, sq, sk, km, nseq, Sq, Sk, H, Dh, o, lse, c->attn_impl, rg.off, rg.rows);
   }
   void attn_bwd(const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq, const float* sk,
                 const float* km, int64_t nseq, int Sq, int Sk, const T* o, const float* lse, const T* d_o, T* dq, T* dk, T* dv,
-                float* dsq, float* dsk) {
-    attention_bwd<T>(c, q, k, v, ldq, ldk, ldv, sq, sk, km, nseq, Sq, Sk, H, Dh, o, lse, d_o, dq, dk, dv, dsq, dsk, c->attn_impl);
+                float* dsq, float* dsk, const Rag& rg = Rag()) {
+    attention_bwd<T>(c, q, k, v, ldq, ldk, ldv, sq, sk, km, nseq, Sq, Sk, H, Dh, o, lse, d_o, dq, dk, dv, dsq, dsk, c->attn_impl, rg.off, rg.rows);
   }
 
   // ------------------------------------------------------------------ ImprovedTransformerBlock (attention.py:67-108)
-  void block_fwd(const BlockW<T>& w, const T* x, T* y, int64_t nseq, int S, const float* km, const T* kv, int Skv, BlockStash<T>* st) {
-    const int64_t M = nseq * S; const int d = w.d;
+  void block_fwd(const BlockW<T>& w, const T* x, T* y, int64_t nseq, int S, const float* km, const T* kv, int Skv, BlockStash<T>* st,
+                 const Rag& rg = Rag()) {
+    const int64_t M = rg.off ? rg.rows : nseq * S, Mg = rg.off ? (M + 7) & ~int64_t(7) : M; const int d = w.d;  // Mg: NT-GEMM rows (see Rag)
     int64_t mk = c->ar.mark();
-    T* nq = alloc<T>(M * d); float* st1 = alloc<float>(M * 2);
+    T* nq = alloc<T>(Mg * d); float* st1 = alloc<float>(M * 2);
     k_layernorm<T>(c, x, w.norm_q, nq, st1, M, d);                                      // :76-78
-    T* qkv = alloc<T>(M * 3 * E);
-    lin_fwd(w.qkv, nq, qkv, M);                                                         // :154-173
-    T* o = alloc<T>(M * E); float* lse = alloc<float>(M * H * 2);
-    attn_fwd(qkv, qkv + E, qkv + 2 * E, 3 * E, 3 * E, 3 * E, w.sq, w.sk, km, nseq, S, S, o, lse);  // :166-175
-    T* a = alloc<T>(M * d);
-    lin_fwd(w.out, o, a, M, EPI_NONE, x);                                               // :178-183 + residual :79,90
+    T* qkv = alloc<T>(Mg * 3 * E);
+    lin_fwd(w.qkv, nq, qkv, Mg);                                                         // :154-173
+    T* o = alloc<T>(Mg * E); float* lse = alloc<float>(M * H * 2);
+    attn_fwd(qkv, qkv + E, qkv + 2 * E, 3 * E, 3 * E, 3 * E, w.sq, w.sk, km, nseq, S, S, o, lse, rg);  // :166-175
+    T* a = alloc<T>(Mg * d);
+    lin_fwd(w.out, o, a, Mg, EPI_NONE, x);                                               // :178-183 + residual :79,90
     T *cq = nullptr, *ckv = nullptr, *co = nullptr; float* clse = nullptr;
     if (w.cross) {                                                                      // :92-100
       cq = alloc<T>(M * E); lin_fwd(w.cq, nq, cq, M);
@@ -215,38 +222,38 @@ template <typename T> struct Net {
       attn_fwd(cq, ckv, ckv + E, E, 2 * E, 2 * E, w.csq, w.csk, nullptr, nseq, S, Skv, co, clse);
       lin_fwd(w.cout, co, a, M, EPI_NONE, a);
     }
-    T* na = alloc<T>(M * d); float* st2 = alloc<float>(M * 2);
+    T* na = alloc<T>(Mg * d); float* st2 = alloc<float>(M * 2);
     k_layernorm<T>(c, a, w.norm_attn, na, st2, M, d);                                   // :103-105
-    T* hpre = alloc<T>(M * w.mlp); T* h = alloc<T>(M * w.mlp);
-    lin_fwd(w.mlp_in, na, h, M, EPI_GELU, nullptr, 0, 0, 0, 0, 0, 0, hpre);             // :106  h = gelu(hpre), both kept for the backward
-    lin_fwd(w.mlp_out, h, y, M, EPI_NONE, a);                                           // :107-108
+    T* hpre = alloc<T>(Mg * w.mlp); T* h = alloc<T>(Mg * w.mlp);
+    lin_fwd(w.mlp_in, na, h, Mg, EPI_GELU, nullptr, 0, 0, 0, 0, 0, 0, hpre);             // :106  h = gelu(hpre), both kept for the backward
+    lin_fwd(w.mlp_out, h, y, Mg, EPI_NONE, a);                                           // :107-108
     if (st) { st->x = const_cast<T*>(x); st->nq = nq; st->qkv = qkv; st->o = o; st->a = a; st->na = na; st->hpre = hpre; st->h = h;
               st->st1 = st1; st->st2 = st2; st->cq = cq; st->ckv = ckv; st->co = co; st->lse = lse; st->clse = clse; }
     else c->ar.release(mk);
   }
   // dy -> dx (dx may alias dy); dkv accumulated (T) if cross
   void block_bwd(const BlockW<T>& w, const BlockStash<T>& s, const T* dy, T* dx, int64_t nseq, int S, const float* km, const T* kv,
-                 int Skv, T* dkv) {
-    const int64_t M = nseq * S; const int d = w.d;
+                 int Skv, T* dkv, const Rag& rg = Rag()) {
+    const int64_t M = rg.off ? rg.rows : nseq * S, Mg = rg.off ? (M + 7) & ~int64_t(7) : M; const int d = w.d;
     int64_t mk = c->ar.mark();
     lin_bwd_w(w.mlp_out, s.h, dy, M);
-    T* dh = alloc<T>(M * w.mlp);  // dh = dy Wout^T * gelu'(hpre)
-    lin_bwd_x(w.mlp_out, dy, dh, M, s.hpre);
+    T* dh = alloc<T>(Mg * w.mlp);  // dh = dy Wout^T * gelu'(hpre)
+    lin_bwd_x(w.mlp_out, dy, dh, Mg, s.hpre);
     lin_bwd_w(w.mlp_in, s.na, dh, M);
-    T* dna = alloc<T>(M * d);
-    lin_bwd_x(w.mlp_in, dh, dna, M);
-    T* da = alloc<T>(M * d);
+    T* dna = alloc<T>(Mg * d);
+    lin_bwd_x(w.mlp_in, dh, dna, Mg);
+    T* da = alloc<T>(Mg * d);
     k_layernorm_bwd<T>(c, s.a, w.norm_attn, s.st2, dna, da, w.g_norm_attn, M, d, dy);  // da = dy + LNbwd
     T* dnq = dna;  // reuse
     // self attention
     lin_bwd_w(w.out, s.o, da, M);
-    T* d_o = alloc<T>(M * E);
-    lin_bwd_x(w.out, da, d_o, M);
-    T* dqkv = alloc<T>(M * 3 * E);
+    T* d_o = alloc<T>(Mg * E);
+    lin_bwd_x(w.out, da, d_o, Mg);
+    T* dqkv = alloc<T>(Mg * 3 * E);
     attn_bwd(s.qkv, s.qkv + E, s.qkv + 2 * E, 3 * E, 3 * E, 3 * E, w.sq, w.sk, km, nseq, S, S, s.o, s.lse, d_o, dqkv, dqkv + E,
-             dqkv + 2 * E, w.g_sq, w.g_sk);
+             dqkv + 2 * E, w.g_sq, w.g_sk, rg);
     lin_bwd_w(w.qkv, s.nq, dqkv, M);
-    lin_bwd_x(w.qkv, dqkv, dnq, M);
+    lin_bwd_x(w.qkv, dqkv, dnq, Mg);
     if (w.cross) {
       lin_bwd_w(w.cout, s.co, da, M);
       lin_bwd_x(w.cout, da, d_o, M);  // d_o := d co
@@ -268,21 +275,27 @@ template <typename T> struct Net {
   // ------------------------------------------------------------------ last block of a stack whose output is token 0 only
   // (track_autoencoder_3d.py:187-188, 286).  K/V (and LN1) still cover every token; the query, attention output,
   // out-projection, LN2 and MLP are needed for row 0 of each sequence only: 25 % of a full block's GEMM work.
-  struct LastStash { T *x, *nq, *kv, *q0, *o0, *x0, *a0, *na0, *hpre0, *h0; float *st1, *st2, *p0; };
-  void block_fwd_last(const BlockW<T>& w, const T* x, T* y0, int64_t nseq, int S, const float* km, LastStash* st) {
-    const int64_t M = nseq * S; const int d = w.d;
+  struct LastStash { T *x, *nq, *kv, *q0, *o0, *x0, *a0, *na0, *hpre0, *h0, *nq0 = nullptr; float *st1, *st2, *p0; };
+  void block_fwd_last(const BlockW<T>& w, const T* x, T* y0, int64_t nseq, int S, const float* km, LastStash* st, const Rag& rg = Rag()) {
+    const int64_t M = rg.off ? rg.rows : nseq * S, Mg = rg.off ? (M + 7) & ~int64_t(7) : M; const int d = w.d;
     const int64_t mk = c->ar.mark();
     const Lin<T> wq = sub_lin(w.qkv, 0, 1), wkv = sub_lin(w.qkv, 1, 2);
-    T* nq = alloc<T>(M * d); float* st1 = alloc<float>(M * 2);
+    T* nq = alloc<T>(Mg * d); float* st1 = alloc<float>(M * 2);
     k_layernorm<T>(c, x, w.norm_q, nq, st1, M, d);
-    T* kv = alloc<T>(M * 2 * E);
-    lin_fwd(wkv, nq, kv, M);
-    T* q0 = alloc<T>(nseq * E);
-    lin_fwd(wq, nq, q0, nseq, EPI_NONE, nullptr, 0, 0, (int64_t)S * d);          // rows 0 of every sequence
+    T* kv = alloc<T>(Mg * 2 * E);
+    lin_fwd(wkv, nq, kv, Mg);
+    T* q0 = alloc<T>(nseq * E); T* nq0 = nullptr;
+    if (rg.off) {  // rows 0 of the ragged sequences sit at seq_off[i]
+      nq0 = alloc<T>(nseq * d);
+      k_rows_idx<T>(c, 0, nq, rg.off, nq0, nseq, d);
+      lin_fwd(wq, nq0, q0, nseq);
+    } else {
+      lin_fwd(wq, nq, q0, nseq, EPI_NONE, nullptr, 0, 0, (int64_t)S * d);          // rows 0 of every sequence
+    }
     T* o0 = alloc<T>(nseq * E); float* p0 = alloc<float>(nseq * H * S);
-    k_attn_q1_fwd<T>(c, q0, E, kv, kv + E, 2 * E, 2 * E, w.sq, w.sk, km, nseq, S, H, Dh, o0, p0);
+    k_attn_q1_fwd<T>(c, q0, E, kv, kv + E, 2 * E, 2 * E, w.sq, w.sk, km, nseq, S, H, Dh, o0, p0, rg.off);
     T* x0 = alloc<T>(nseq * d);
-    k_gather_rows<T>(c, x, S, x0, nseq, d);
+    if (rg.off) k_rows_idx<T>(c, 0, x, rg.off, x0, nseq, d); else k_gather_rows<T>(c, x, S, x0, nseq, d);
     T* a0 = alloc<T>(nseq * d);
     lin_fwd(w.out, o0, a0, nseq, EPI_NONE, x0);
     T* na0 = alloc<T>(nseq * d); float* st2 = alloc<float>(nseq * 2);
@@ -291,12 +304,12 @@ template <typename T> struct Net {
     lin_fwd(w.mlp_in, na0, h0, nseq, EPI_GELU, nullptr, 0, 0, 0, 0, 0, 0, hpre0);
     lin_fwd(w.mlp_out, h0, y0, nseq, EPI_NONE, a0);
     if (st) { st->x = const_cast<T*>(x); st->nq = nq; st->kv = kv; st->q0 = q0; st->o0 = o0; st->x0 = x0; st->a0 = a0; st->na0 = na0;
-              st->hpre0 = hpre0; st->h0 = h0; st->st1 = st1; st->st2 = st2; st->p0 = p0; }
+              st->hpre0 = hpre0; st->h0 = h0; st->st1 = st1; st->st2 = st2; st->p0 = p0; st->nq0 = nq0; }
     else c->ar.release(mk);
   }
-  // dy0 [nseq,d] -> dx [nseq*S, d]
-  void block_bwd_last(const BlockW<T>& w, const LastStash& s, const T* dy0, T* dx, int64_t nseq, int S, const float* km) {
-    const int64_t M = nseq * S; const int d = w.d;
+  // dy0 [nseq,d] -> dx [rows of the stack input, d]
+  void block_bwd_last(const BlockW<T>& w, const LastStash& s, const T* dy0, T* dx, int64_t nseq, int S, const float* km, const Rag& rg = Rag()) {
+    const int64_t M = rg.off ? rg.rows : nseq * S, Mg = rg.off ? (M + 7) & ~int64_t(7) : M; const int d = w.d;
     const int64_t mk = c->ar.mark();
     const Lin<T> wq = sub_lin(w.qkv, 0, 1), wkv = sub_lin(w.qkv, 1, 2);
     lin_bwd_w(w.mlp_out, s.h0, dy0, nseq);
@@ -310,15 +323,24 @@ template <typename T> struct Net {
     lin_bwd_w(w.out, s.o0, da0, nseq);
     T* d_o0 = alloc<T>(nseq * E);
     lin_bwd_x(w.out, da0, d_o0, nseq);
-    T* dq0 = alloc<T>(nseq * E); T* dkv = alloc<T>(M * 2 * E);
-    k_attn_q1_bwd<T>(c, s.q0, E, s.kv, s.kv + E, 2 * E, 2 * E, w.sq, w.sk, km, nseq, S, H, Dh, s.p0, d_o0, dq0, dkv, dkv + E, w.g_sq, w.g_sk);
+    T* dq0 = alloc<T>(nseq * E); T* dkv = alloc<T>(Mg * 2 * E);
+    k_attn_q1_bwd<T>(c, s.q0, E, s.kv, s.kv + E, 2 * E, 2 * E, w.sq, w.sk, km, nseq, S, H, Dh, s.p0, d_o0, dq0, dkv, dkv + E, w.g_sq, w.g_sk,
+                     rg.off);
     lin_bwd_w(wkv, s.nq, dkv, M);
-    lin_bwd_w(wq, s.nq, dq0, nseq, (int64_t)S * d);
-    T* dnq = alloc<T>(M * d);
-    lin_bwd_x(wkv, dkv, dnq, M);
-    lin_bwd_x(wq, dq0, dnq, nseq, nullptr, 1, (int64_t)S * d);                    // += into rows 0
+    T* dnq = alloc<T>(Mg * d);
+    lin_bwd_x(wkv, dkv, dnq, Mg);
+    if (rg.off) {
+      lin_bwd_w(wq, s.nq0, dq0, nseq);
+      T* dnq0 = alloc<T>(nseq * d);
+      lin_bwd_x(wq, dq0, dnq0, nseq);
+      k_rows_idx<T>(c, 2, dnq0, rg.off, dnq, nseq, d);                             // += into rows 0
+    } else {
+      lin_bwd_w(wq, s.nq, dq0, nseq, (int64_t)S * d);
+      lin_bwd_x(wq, dq0, dnq, nseq, nullptr, 1, (int64_t)S * d);                  // += into rows 0
+    }
     k_layernorm_bwd<T>(c, s.x, w.norm_q, s.st1, dnq, dx, w.g_norm_q, M, d, nullptr);
-    k_add_rows_strided<T>(c, dx, da0, S, nseq, d);                                 // residual path of token 0
+    if (rg.off) k_rows_idx<T>(c, 2, da0, rg.off, dx, nseq, d);                     // residual path of token 0
+    else k_add_rows_strided<T>(c, dx, da0, S, nseq, d);
     c->ar.release(mk);
   }
 
@@ -328,6 +350,7 @@ template <typename T> struct Net {
     // encoder
     T* sinbuf; const void* dino; const void* depthf; float* km; T* tok0; std::vector<BlockStash<T>> enc_st; T* enc_last; T* r0; float* st_r0;
     T* enc_out; LastStash enc_lst, ro_lst; T* enc_ln_all = nullptr; float* st_all = nullptr; const float* sup_vis = nullptr;
+    Rag enc_rg; int32_t* row_src = nullptr;  // token pruning of the track encoder (encode_chunk)
     // t2l
     T* lat_in; std::vector<BlockStash<T>> t2l_st; T* t2l_last; float* st_t2l; T* t2l_n; float* latents;  // [Bc,L,Ld] f32
     // decode
@@ -344,6 +367,22 @@ template <typename T> struct Net {
     k.sup_vis = b->support_tracks_visible + b0 * k.N * T_;
     k.sinbuf = alloc<T>(nseq * T_ * (NC + 1) * 2 * nf);
     k_embed_tokens<T>(c, tracks, nseq * T_, T_, nf, g.track_scale_factor, k.sinbuf, NC);             // 3d:126-134 / ta:186-199
+    k.km = alloc<float>(nseq * S);
+    if (twoD) k_keymask2d(c, k.sup_vis, b->boundary_frame + b0, nseq, k.N, T_, k.km);                // ta:213-223
+    else k_keymask(c, k.sup_vis, b->boundary_frame + b0, nseq, k.N, T_, k.km);                       // 3d:167-180 (R2,R3)
+    // Token pruning (3DSPA, fused 16-bit attention): a frame token whose key is masked is attended to by nobody, and only token 0 leaves
+    // the stack (3d:187-188), so its row influences neither the output nor any gradient: the encoder runs on the kept rows only.
+    k.enc_rg = Rag(); k.row_src = nullptr;
+    const bool can_prune = !twoD && c->prune && sizeof(T) == 2 && Dh == 96 && S <= 320 && c->attn_impl != 1;
+    if (can_prune) {
+      int32_t* cnt = alloc<int32_t>(nseq); int32_t* off = alloc<int32_t>(nseq + 1); k.row_src = alloc<int32_t>(nseq * S);
+      const int64_t kept = k_prune_plan(c, k.km, nseq, S, cnt, off, k.row_src);
+      if (c->dry || kept < nseq * S) { k.enc_rg.off = off; k.enc_rg.rows = kept; }   // (the sizing dry run takes this branch at the dense count)
+    }
+    const Rag& rg = k.enc_rg;
+    const int64_t rows = rg.off ? rg.rows : nseq * S, rows_g = rg.off ? (rows + 7) & ~int64_t(7) : rows;
+    T* tokc = rg.off ? alloc<T>(rows_g * d) : nullptr;
+    const int64_t mk_dense = c->ar.mark();
     k.tok0 = alloc<T>(nseq * S * d);
     // 3DSPA: rows 1..T of every sequence <- Dense(sin) [+ Dense(dino)] [+ Dense(depth)] (3d:137-147); TRAJAN: rows 0..T-1 (ta:211)
     const int cg = twoD ? 0 : T_, cs = twoD ? 0 : 1;
@@ -359,22 +398,22 @@ template <typename T> struct Net {
       if (!(sizeof(T) == 2 && depth.ldn == depth.N && k_rank_fwd<T>(c, (const T*)k.depthf, depth.wn, depth.bias, k.tok0, nseq * T_, depth.N, depth.K, d, T_, 1)))
         lin_fwd(depth, (const T*)k.depthf, k.tok0, nseq * T_, EPI_NONE, nullptr, 0, 1, 0, 0, T_, 1);
     }
-    k.km = alloc<float>(nseq * S);
-    if (twoD) {
-      k_keymask2d(c, k.sup_vis, b->boundary_frame + b0, nseq, k.N, T_, k.km);                        // ta:213-223
-    } else {
-      k_set_readout_rows<T>(c, k.tok0, readout, nseq, S, d);                                         // 3d:161-165
-      k_keymask(c, k.sup_vis, b->boundary_frame + b0, nseq, k.N, T_, k.km);                          // 3d:167-180 (R2,R3)
-    }
+    if (!twoD) k_set_readout_rows<T>(c, k.tok0, readout, nseq, S, d);                                // 3d:161-165
     const T* x = k.tok0;
+    const float* km = k.km;
+    if (rg.off) {  // compact, then the dense token tensor is dead (the backward rebuilds a dense gradient for the embed dW)
+      k_rows_idx<T>(c, 0, k.tok0, k.row_src, tokc, rows, d);
+      c->ar.release(mk_dense);
+      k.tok0 = tokc; x = tokc; km = nullptr;  // every kept key is visible
+    }
     const int nenc = (int)enc.blocks.size();
     const int nfull = twoD ? nenc : nenc - 1;  // TRAJAN pools over every frame token: no pruned last block
     k.enc_st.resize(nenc);
     T* pp[2] = {nullptr, nullptr};
-    if (!train && nfull > 0) { pp[0] = alloc<T>(nseq * S * d); if (nfull > 1) pp[1] = alloc<T>(nseq * S * d); }
+    if (!train && nfull > 0) { pp[0] = alloc<T>(rows_g * d); if (nfull > 1) pp[1] = alloc<T>(rows_g * d); }
     for (int i = 0; i < nfull; ++i) {
-      T* y = train ? alloc<T>(nseq * S * d) : pp[i & 1];
-      block_fwd(enc.blocks[i], x, y, nseq, S, k.km, nullptr, 0, train ? &k.enc_st[i] : nullptr);
+      T* y = train ? alloc<T>(rows_g * d) : pp[i & 1];
+      block_fwd(enc.blocks[i], x, y, nseq, S, km, nullptr, 0, train ? &k.enc_st[i] : nullptr, rg);
       x = y;
     }
     k.enc_last = const_cast<T*>(x);
@@ -385,7 +424,7 @@ template <typename T> struct Net {
       k_vis_mean_pool<T>(c, k.enc_ln_all, k.sup_vis, nseq, T_, d, k.enc_out);                        // ta:230-232
     } else {
       k.r0 = alloc<T>(nseq * d); k.st_r0 = alloc<float>(nseq * 2);
-      block_fwd_last(enc.blocks[nenc - 1], x, k.r0, nseq, S, k.km, train ? &k.enc_lst : nullptr);    // token 0 only: 3d:187-188
+      block_fwd_last(enc.blocks[nenc - 1], x, k.r0, nseq, S, km, train ? &k.enc_lst : nullptr, rg);  // token 0 only: 3d:187-188
       k_layernorm<T>(c, k.r0, enc.norm_enc, k.enc_out, k.st_r0, nseq, d);                            // attention.py:49-51 (row 0 only)
     }
     // L1-L3
@@ -512,7 +551,8 @@ template <typename T> struct Net {
     k_bcast_grad<T>(c, dt2l, (int64_t)L * dl, k.Bc, (int64_t)L * dl, g_lat0);
     // ---- track encoder
     const int S = k.S;
-    T* dtok = alloc<T>(nseq * S * d);
+    const int64_t erows = k.enc_rg.off ? (k.enc_rg.rows + 7) & ~int64_t(7) : nseq * S;
+    T* dtok = alloc<T>(erows * d);
     const int nenc = (int)enc.blocks.size();
     if (twoD) {
       T* dln = alloc<T>(nseq * S * d);
@@ -524,15 +564,28 @@ template <typename T> struct Net {
     } else {
       T* dr0 = alloc<T>(nseq * d);
       k_layernorm_bwd<T>(c, k.r0, enc.norm_enc, k.st_r0, denc_out, dr0, enc.g_norm_enc, nseq, d, nullptr);
-      block_bwd_last(enc.blocks[nenc - 1], k.enc_lst, dr0, dtok, nseq, S, k.km);
+      const Rag& rg = k.enc_rg;
+      const float* km = rg.off ? nullptr : k.km;
+      block_bwd_last(enc.blocks[nenc - 1], k.enc_lst, dr0, dtok, nseq, S, km, rg);
       for (int i = nenc - 2; i >= 0; --i)
-        block_bwd(enc.blocks[i], k.enc_st[i], dtok, dtok, nseq, S, k.km, nullptr, 0, nullptr);
-      k_bcast_grad<T>(c, dtok, d, nseq, (int64_t)S * d, g_readout);
+        block_bwd(enc.blocks[i], k.enc_st[i], dtok, dtok, nseq, S, km, nullptr, 0, nullptr, rg);
+      const T* dtok_dense = dtok;
+      if (rg.off) {
+        T* d0 = alloc<T>(nseq * d);                                                    // rows 0 -> the readout token's gradient
+        k_rows_idx<T>(c, 0, dtok, rg.off, d0, nseq, d);
+        k_bcast_grad<T>(c, d0, d, nseq, d, g_readout);
+        T* dd = alloc<T>(nseq * S * d);                                                // dense gradient for the embed dW (pruned rows: 0)
+        k_zero(c, dd, nseq * S * d * (int64_t)sizeof(T));
+        k_rows_idx<T>(c, 1, dtok, k.row_src, dd, rg.rows, d);
+        dtok_dense = dd;
+      } else {
+        k_bcast_grad<T>(c, dtok, d, nseq, (int64_t)S * d, g_readout);
+      }
       // token rows 1..T of every sequence (row remap on the reduction index: no compaction copy)
-      lin_bwd_w(tok, k.sinbuf, dtok, nseq * T_, 0, T_, 1);
-      if (k.dino) lin_bwd_w(dino, (const T*)k.dino, dtok, nseq * T_, 0, T_, 1);
-      if (k.depthf && !(sizeof(T) == 2 && depth.nseg == 1 && k_rank_bwd<T>(c, (const T*)k.depthf, dtok, nseq * T_, depth.N, depth.K, d, T_, 1, depth.gw[0], depth.gb)))
-        lin_bwd_w(depth, (const T*)k.depthf, dtok, nseq * T_, 0, T_, 1);
+      lin_bwd_w(tok, k.sinbuf, dtok_dense, nseq * T_, 0, T_, 1);
+      if (k.dino) lin_bwd_w(dino, (const T*)k.dino, dtok_dense, nseq * T_, 0, T_, 1);
+      if (k.depthf && !(sizeof(T) == 2 && depth.nseg == 1 && k_rank_bwd<T>(c, (const T*)k.depthf, dtok_dense, nseq * T_, depth.N, depth.K, d, T_, 1, depth.gw[0], depth.gb)))
+        lin_bwd_w(depth, (const T*)k.depthf, dtok_dense, nseq * T_, 0, T_, 1);
     }
     c->ar.release(mk0);
   }
@@ -745,6 +798,7 @@ int spa3d_create(const spa3d_config* cfg, spa3d_handle* out) {
   e = getenv("SPA3D_LOSS_SCALE"); if (e && cfg->precision == SPA3D_F16) c->loss_scale = (float)atof(e);
   e = getenv("SPA3D_ATTN_IMPL"); if (e) c->attn_impl = atoi(e);
   e = getenv("SPA3D_ATTN_BWD_MODE"); if (e) c->attn_bwd_mode = atoi(e);
+  e = getenv("SPA3D_PRUNE"); if (e) c->prune = atoi(e);
   e = getenv("SPA3D_NT_OCC"); if (e) c->nt_occ = atoi(e);
   e = getenv("SPA3D_NT_8P"); if (e) c->nt_8p = atoi(e);
   e = getenv("SPA3D_NT_8PP"); if (e) c->nt_8pp = atoi(e);

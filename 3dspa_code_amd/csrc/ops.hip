@@ -71,11 +71,12 @@ int op_linear_bwd(OpCtx& c, const T* A, const T* B, const T* dC, T* dA, float* d
 // attention front ends live in attention.hip
 template <typename T>
 void attention_fwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq,
-                   const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, T* o, float* lse, int impl);
+                   const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, T* o, float* lse, int impl,
+                   const int32_t* seq_off = nullptr, int64_t total_rows = 0);
 template <typename T>
 void attention_bwd(spa3d_ctx* c, const T* q, const T* k, const T* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq,
                    const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, const T* o, const float* lse, const T* d_o,
-                   T* dq, T* dk, T* dv, float* dsq, float* dsk, int impl);
+                   T* dq, T* dk, T* dv, float* dsq, float* dsk, int impl, const int32_t* seq_off = nullptr, int64_t total_rows = 0);
 }  // namespace SPA_NS
 
 // The entry points below are compiled twice: as declared in include/spa3d.h (this build's 16-bit type is bf16) and, with
