@@ -220,6 +220,10 @@ def test_cfg1_bf16_tiled_vs_generic_and_fp32(spa3d, monkeypatch):
   cos = float((g_fast.double() @ g_g.flat.double()) / (g_fast.double().norm() * g_g.flat.double().norm()))
   print('bf16 tiled vs generic: tracks rel', e, 'grad cosine', cos)
   assert e < 2e-2 and cos > 0.995
+  fa, fb = O.tree_flatten(g_f), O.tree_flatten(g_g)
+  worst = max((rel_err(fa[k].float(), fb[k].float()), k) for k in fb if float(fb[k].float().norm()) > 1e-12)
+  print('bf16 tiled vs generic: worst gradient leaf', worst)
+  assert worst[0] < 0.25
   m32 = product_model(spa3d, cfg, 'fp32')
   gb32 = dict(gb)
   gb32['dino_features'] = gb['dino_features'].float()
@@ -263,6 +267,11 @@ def test_cfg1_bf16_forced_8phase_kernels_vs_generic(spa3d, monkeypatch):
   print('bf16 forced 8-phase vs generic: tracks rel', e, 'grad cosine', cos)
   assert e < 2e-2 and cos > 0.995
   assert torch.isfinite(g_fast).all()
+  # every gradient leaf, not only the whole-gradient direction: a wrong small leaf (a norm scale, the readout token) cannot hide
+  fa, fb = O.tree_flatten(g_f), O.tree_flatten(g_g)
+  worst = max((rel_err(fa[k].float(), fb[k].float()), k) for k in fb if float(fb[k].float().norm()) > 1e-12)
+  print('bf16 forced 8-phase vs generic: worst gradient leaf', worst)
+  assert worst[0] < 0.25  # two bf16 paths with different summation orders through 11 blocks (T=150 tests: 8 % vs the fp32 path)
 
   # the bias gradients ride along in the 8-phase dW kernel (column sums of dY): leaf by leaf against the generic path's colsum kernel
   def walk(a, b, path=''):
