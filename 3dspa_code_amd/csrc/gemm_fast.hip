@@ -42,6 +42,9 @@ struct NtArgs {
   int64_t M; int N; int K; int64_t lda, ldb, ldc;
   const float* bias; const bf16_t* aux; bf16_t* pre_out; int epi; int out_f32; int accumulate; float alpha;
   int tiles_m, tiles_n, crow_group, crow_skip;
+#ifdef SPA3D_ABLATE
+  int ablate;
+#endif
   int nt_store;  // bf16 output with non-temporal stores: a streamed output far larger than the caches (+3-6 % measured at K = 384)
 };
 
@@ -420,6 +423,12 @@ __device__ __forceinline__ void nt_store4(const NtArgs& g, int64_t gm, int gn, c
   }
 }
 
+// diagnostic library only (tools/ablate_gemm.py, -DSPA3D_ABLATE): the persistent kernel without its output stores = loop-only time
+#ifdef SPA3D_ABLATE
+#define NT_ABLATE_STORES && !g.ablate
+#else
+#define NT_ABLATE_STORES
+#endif
 #define NT8P_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define NT8P_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define NT8P_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
@@ -882,7 +891,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           const int64_t gm = cm0 + (rbase + (p / CS) * 16 + prow[it]);
-          if (pval[it] && gm < g.M) {
+          if (pval[it] && gm < g.M NT_ABLATE_STORES) {
             u32x4* cp = (u32x4*)((bf16_t*)g.C + gm * g.ldc + gn_of(p % CS, it));
             const u32x4 o = u32x4{held[p][it].x, held[p][it].y, held[p][it].z, held[p][it].w};
             if (g.nt_store) __builtin_nontemporal_store(o, cp); else *cp = o;
@@ -896,7 +905,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
         for (int it = 0; it < 2; ++it) {
           float v[8]; read_item(it, v);
           const int64_t gm = cm0 + (rbase + (p / CS) * 16 + prow[it]);
-          if (pval[it] && gm < g.M) nt_store8<true, false>(g, gm, gn_of(p % CS, it), v, b8[p % CS][it]);
+          if (pval[it] && gm < g.M NT_ABLATE_STORES) nt_store8<true, false>(g, gm, gn_of(p % CS, it), v, b8[p % CS][it]);
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -904,8 +913,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8pp_kernel(NtArgs g) {
     if (!more) break;
     // the next tile's first K-tile has landed when only its second K-tile and this epilogue's stores can still be outstanding
     if (!interior) NT8P_WAIT_VM(0);
-    else if (nst_code) NT8P_WAIT_VM(NKT + 32);
-    else NT8P_WAIT_VM(NKT + 16);
+    else if (nst_code) NT8P_WAIT_VM(NKT + 4 * NP);   // two outputs (or f32): 4 NP 16-byte stores per lane and tile
+    else NT8P_WAIT_VM(NKT + 2 * NP);
   }
 }
 
@@ -930,6 +939,9 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   g.bias = d.bias; g.aux = (const bf16_t*)d.aux; g.pre_out = (bf16_t*)d.pre_out; g.epi = d.epi; g.out_f32 = d.out_f32; g.accumulate = d.accumulate; g.alpha = d.alpha;
   g.tiles_m = (int)((d.M + 127) / 128); g.tiles_n = (d.N + 127) / 128;
   g.crow_group = d.crow_group; g.crow_skip = d.crow_skip;
+#ifdef SPA3D_ABLATE
+  { const char* e = getenv("SPA3D_ABLATE"); g.ablate = e ? atoi(e) : 0; }
+#endif
   g.nt_store = (!d.out_f32 && (double)d.M * d.N * 2.0 >= 512e6 && c->nt_stream) ? 1 : 0;
   const int64_t blocks = (int64_t)((g.tiles_m + 7) / 8) * 8 * g.tiles_n;
   if (blocks > 0x7fffffffLL) return false;
