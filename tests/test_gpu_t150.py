@@ -195,3 +195,43 @@ def test_token_pruning_equals_the_dense_encoder(monkeypatch, precision):
   print(f'pruned vs dense [{precision}]: tracks rel {e_t:.3e} latents rel {e_l:.3e} loss {l1} vs {l0}; worst gradient leaf {worst}')
   assert e_t < tol and e_l < tol and abs(l1 - l0) < tol * abs(l0)
   assert worst[0] < (0.30 if precision == 'bf16' else 0.04)
+
+
+@pytest.mark.gpu
+def test_token_pruning_edge_cases(monkeypatch):
+  """Ragged extremes: a sample with boundary_frame = 0 (every frame token masked: all its sequences shrink to the readout token alone),
+  tracks that are never visible, a fully visible track, 13 sequences (not a multiple of 8: the XCD-major problem map's identity tail).
+  Pruned vs dense in fp16, and both against the fp64 oracle."""
+  import spa3d
+  cfg = O.Config(num_output_frames=24, use_dino=True, use_depth=True, dino_feature_dim=768, depth_feature_dim=1)
+  B, N, Q, T = 3, 13, 4, 24
+  batch = O.synthetic_batch(B, N, Q, T, seed=4242, dino_dim=768, depth_dim=1)
+  batch['boundary_frame'] = torch.tensor([0, 24, 7], dtype=torch.int32)
+  batch['support_tracks_visible'][1, 0] = 0.0     # never visible
+  batch['support_tracks_visible'][1, 1] = 1.0     # always visible
+  batch['support_tracks_visible'][2, :, :7] = 0.0  # nothing visible before the boundary either
+  for k in ('dino_features', 'depth_features'):
+    batch[k] = batch[k].half().float()
+  p = O.init_params(cfg, seed=9, dtype=torch.float32, depth_dim=1, perturb=0.1)
+  noise = torch.rand(B, cfg.num_latent_tokens, cfg.latent_token_dim, generator=torch.Generator().manual_seed(2))
+  p64 = O.tree_map(lambda t: t.double(), p)
+  b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+  ld_ref, preds_ref, grads_ref = O.loss_and_grads(O.TrackAutoEncoder3D(cfg), p64, b64, discretize=True, noise=noise.double())
+  runs = {}
+  for prune in ('1', '0'):
+    monkeypatch.setenv('SPA3D_PRUNE', prune)
+    model = product_model(spa3d, cfg, 'fp16')
+    gb = batch_to(batch, 'cuda')
+    for k in ('dino_features', 'depth_features'):
+      gb[k] = gb[k].half()
+    gp = O.tree_map(lambda t: t.cuda(), p)
+    ld, grads, preds = model.loss_and_grads({'params': gp}, gb, noise=noise.cuda(), return_predictions=True)
+    torch.cuda.synchronize()
+    runs[prune] = (float(ld['total_loss']), O.tree_flatten(grads), preds.tracks.clone())
+  for prune, (l, g, t) in runs.items():
+    e = rel_err(t, preds_ref.tracks)
+    worst = max((rel_err(g[k], grads_ref[k]), k) for k in grads_ref if float(grads_ref[k].norm()) > 1e-9)
+    print(f'prune={prune}: tracks rel vs oracle {e:.3e}, loss {l} vs {float(ld_ref["total_loss"])}, worst gradient leaf {worst}')
+    assert e < 5e-3 and abs(l - float(ld_ref['total_loss'])) < 1e-3 * abs(float(ld_ref['total_loss']))
+    assert worst[0] < 0.08 and all(bool(torch.isfinite(v).all()) for v in g.values())
+  assert rel_err(runs['1'][2], runs['0'][2]) < 3e-3
