@@ -278,7 +278,205 @@ static void launch_fwd(spa3d_ctx* c, const AttnArgs& a) {
   attn_fwd_kernel<KT, NW><<<(unsigned)a.nprob, NW * 64, lds, c->stream>>>(a);
 }
 
+
+// =================================================================================================================
+// cross attention (tracks_to_latents, track_autoencoder_3d.py:95-100,201: 128 latent queries against the N = 2048 track tokens of a
+// sample; attention.py:92-100).  Sq <= 128 query rows, Sk keys cut into chunks of 128: one workgroup per (sequence, head, chunk) runs the
+// forward tile routine of attn_fwd_kernel<8, 4> on its chunk and leaves an UNNORMALISED partial (sum_k exp(s - m_chunk) v, m_chunk,
+// sum_k exp(s - m_chunk)); xattn_combine_kernel merges the chunks (the split-softmax identity) and writes o and (max, log-sum).
+// Replaces a five-launch composition of strided GEMMs and row kernels that ran at 14-40 TFLOP/s (1.4 ms -> < 0.1 ms per block).
+// =================================================================================================================
+constexpr int XCHUNK = 128;
+struct XAttnArgs {
+  const bf16_t *q, *k, *v; int64_t ldq, ldk, ldv;
+  const float *sq, *sk, *km;
+  int Sq, Sk, H, nsplit; int64_t nprob;
+  float* opart;   // [nprob][nsplit][Sq][96]
+  float* mlpart;  // [nprob][nsplit][Sq][2]
+};
+
+__global__ __launch_bounds__(256, 2) void xattn_fwd_kernel(XAttnArgs g) {
+  constexpr int KT = XCHUNK / 16, NW = 4, S_pad = XCHUNK, RPP = NW * 16, NP = S_pad / RPP, NT = KT / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem; char* Vs = smem + S_pad * ROWB; float* kbias = (float*)(smem + 2 * S_pad * ROWB);
+  const int64_t pi = blockIdx.x, prob = pi / g.nsplit; const int sp = (int)(pi - prob * g.nsplit);
+  const int64_t seq = prob / g.H; const int h = (int)(prob - seq * g.H);
+  const int64_t qrow0 = seq * g.Sq, krow0 = seq * g.Sk + (int64_t)sp * S_pad;
+  const int Sq = g.Sq, kn = min(S_pad, g.Sk - sp * S_pad), QT = (Sq + 15) / 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  RawRows<NP> rk, rv;
+  rows_load<NP, RPP>(rk, g.k + krow0 * g.ldk + h * DH, g.ldk, kn);
+  rows_load<NP, RPP>(rv, g.v + krow0 * g.ldv + h * DH, g.ldv, kn);
+  u16x8 qx[NT][3];
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+    int qrow = (w + NW * it) * 16 + fr; if (qrow > Sq - 1) qrow = Sq - 1;
+    const bf16_t* qp = g.q + (qrow0 + qrow) * g.ldq + h * DH + fq * 8;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) qx[it][s] = *(const u16x8*)(qp + s * 32);
+  }
+  rows_store<true, NP, RPP>(rk, S_pad, g.sk, Ks);
+  rows_store<false, NP, RPP>(rv, S_pad, nullptr, Vs);
+  for (int t = tid; t < S_pad; t += NW * 64) {
+    float b = 0.f;
+    if (t >= kn) b = -__builtin_inff();
+    else if (g.km && g.km[krow0 + t] == 0.f) b = NEG_BIG;
+    kbias[t] = b;
+  }
+  __syncthreads();
+  const float qscale = 0.10206207261596575f;  // 1/sqrt(96)
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+    const int qt = w + NW * it;
+    if (qt < QT) {
+      const int q0 = qt * 16;
+      mfma16x8 qb[3];
+      frag_norm(qx[it], g.sq, fq, qb);
+      f32x4 acc[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const mfma16x8 kf = *(const mfma16x8*)(Ks + (kt * 16 + fr) * ROWB + (s * 32 + fq * 8) * 2);
+          acc[kt] = MFMA16(kf, qb[s], acc[kt]);
+        }
+      }
+      float m = NEG_BIG;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const f32x4 b4 = *(const f32x4*)(kbias + kt * 16 + fq * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[kt][r] = acc[kt][r] * qscale + b4[r]; m = fmaxf(m, acc[kt][r]); }
+      }
+      m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float l = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float p = __expf(acc[kt][r] - m); acc[kt][r] = p; l += p; }
+      l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+      const bool live = q0 + fr < Sq;
+      if (fq == 0 && live) { float* mp = g.mlpart + (pi * Sq + q0 + fr) * 2; mp[0] = m; mp[1] = l; }
+      mfma16x8 pb[KT / 2];
+#pragma unroll
+      for (int s2 = 0; s2 < KT / 2; ++s2) {
+        u16x8 t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = f2bf(acc[2 * s2 + (j >> 2)][j & 3]);
+        pb[s2] = __builtin_bit_cast(mfma16x8, t);
+      }
+      const int tq = fr >> 2, tp = fr & 3;
+      const char* vbase = Vs + tp * 8 + (4 * fq + tq) * ROWB;
+      float* op = g.opart + (pi * Sq + q0 + fr) * DH + fq * 4;
+      static_for<0, 6>([&](auto dtc) {
+        constexpr int dt = decltype(dtc)::value;
+        f32x4 oacc = f32x4{0.f, 0.f, 0.f, 0.f};
+        uint2 lo[KT / 2], hi[KT / 2];
+        static_for<0, KT / 2>([&](auto sc_) {
+          constexpr int s2 = decltype(sc_)::value;
+          lo[s2] = lds_tr16_b64_o<dt * 32 + 32 * s2 * ROWB>(vbase); hi[s2] = lds_tr16_b64_o<dt * 32 + (32 * s2 + 16) * ROWB>(vbase);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < KT / 2; ++s2) {
+          const uint4 vu = make_uint4(lo[s2].x, lo[s2].y, hi[s2].x, hi[s2].y);
+          oacc = MFMA16(__builtin_bit_cast(mfma16x8, vu), pb[s2], oacc);
+        }
+        if (live) *(f32x4*)(op + dt * 16) = oacc;
+      });
+    }
+  }
+}
+
+// one wave per (sequence, head, query): O = sum_c e^{m_c - M} O_c / L,  M = max_c m_c,  L = sum_c e^{m_c - M} l_c
+__global__ __launch_bounds__(256) void xattn_combine_kernel(const float* __restrict__ opart, const float* __restrict__ mlpart, int nsplit, int Sq, int H,
+                                                            int64_t nrows, bf16_t* __restrict__ o, float* __restrict__ lse) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + w;
+  if (row >= nrows) return;
+  const int64_t prob = row / Sq; const int qi = (int)(row - prob * Sq);
+  const int64_t seq = prob / H; const int h = (int)(prob - seq * H);
+  const float* ml = mlpart + (prob * nsplit * Sq + qi) * 2;  // chunk c at + c * Sq * 2
+  float M = -__builtin_inff();
+  for (int c = lane; c < nsplit; c += 64) M = fmaxf(M, ml[(int64_t)c * Sq * 2]);
+#pragma unroll
+  for (int o_ = 32; o_ > 0; o_ >>= 1) M = fmaxf(M, __shfl_xor(M, o_, 64));
+  float L = 0.f;
+  for (int c = lane; c < nsplit; c += 64) L += ml[(int64_t)c * Sq * 2 + 1] * __expf(ml[(int64_t)c * Sq * 2] - M);
+  L = wave_sum(L);
+  float a0 = 0.f, a1 = 0.f;
+  const float* op = opart + (prob * nsplit * Sq + qi) * DH;
+  for (int c = 0; c < nsplit; ++c) {
+    const float wgt = __expf(ml[(int64_t)c * Sq * 2] - M);
+    const float* oc = op + (int64_t)c * Sq * DH;
+    a0 += wgt * oc[lane];
+    if (lane < DH - 64) a1 += wgt * oc[64 + lane];
+  }
+  const float inv = 1.f / L;
+  bf16_t* orow = o + (seq * Sq + qi) * (int64_t)(H * DH) + h * DH;
+  orow[lane] = f2bf(a0 * inv);
+  if (lane < DH - 64) orow[64 + lane] = f2bf(a1 * inv);
+  if (lse && lane == 0) { float* lp = lse + ((seq * Sq) * H + (int64_t)h * Sq + qi) * 2; lp[0] = M; lp[1] = __logf(L); }
+}
+
+// backward tail of the cross attention: dq^ = sum over key chunks of the partials, then the per-head RMSNorm backward (attention.py:166)
+// and the q-scale gradient.  Grid-stride over rows so that the scale gradient costs 96 atomics per workgroup, not per row.
+__global__ __launch_bounds__(256) void xattn_dq_finish_kernel(const float* __restrict__ dqpart, int nsplit, int Sq, int H, int64_t nrows,
+                                                              const bf16_t* __restrict__ q, int64_t ldq, const float* __restrict__ sq,
+                                                              bf16_t* __restrict__ dq, float* __restrict__ dsq) {
+  __shared__ float red[4][DH];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bool hi = lane < DH - 64;
+  const float sc0 = sq[lane], sc1 = hi ? sq[64 + lane] : 0.f;
+  float a0 = 0.f, a1 = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < nrows; row += (int64_t)gridDim.x * 4) {
+    const int64_t prob = row / Sq; const int qi = (int)(row - prob * Sq);
+    const int64_t seq = prob / H; const int h = (int)(prob - seq * H);
+    const float* dp = dqpart + (prob * nsplit * Sq + qi) * DH;
+    float g0 = 0.f, g1 = 0.f;
+    for (int c = 0; c < nsplit; ++c) { const float* dc = dp + (int64_t)c * Sq * DH; g0 += dc[lane]; if (hi) g1 += dc[64 + lane]; }
+    const bf16_t* xp = q + (seq * Sq + qi) * ldq + h * DH;
+    float x0 = bf2f(xp[lane]), x1 = hi ? bf2f(xp[64 + lane]) : 0.f;
+    const float rr = rsqrtf(wave_sum(x0 * x0 + x1 * x1) / DH + 1e-6f);
+    x0 *= rr; x1 *= rr;
+    const float gx = wave_sum(g0 * sc0 * x0 + g1 * sc1 * x1) / DH;
+    bf16_t* drow = dq + (seq * Sq + qi) * ldq + h * DH;
+    drow[lane] = f2bf(rr * (g0 * sc0 - x0 * gx));
+    if (hi) drow[64 + lane] = f2bf(rr * (g1 * sc1 - x1 * gx));
+    a0 += g0 * x0; a1 += g1 * x1;
+  }
+  red[w][lane] = a0; if (hi) red[w][64 + lane] = a1;
+  __syncthreads();
+  if (tid < DH) atomicAdd(dsq + tid, red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+}
+
 static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+static bool xattn_fwd(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* sq,
+                      const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, bf16_t* o, float* lse, const int32_t* seq_off) {
+  const int nsplit = (Sk + XCHUNK - 1) / XCHUNK;
+  const int64_t nprob = nseq * H;
+  if (seq_off || Sq < 1 || Sq > XCHUNK || Sk < 1 || nprob * nsplit > 0x7fffffffLL) return false;
+  if (ldq % 8 || ldk % 8 || ldv % 8 || !al16(q) || !al16(k) || !al16(v) || !al16(o)) return false;
+  const int64_t mk = c->ar.mark();
+  XAttnArgs a; a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.sq = sq; a.sk = sk; a.km = km;
+  a.Sq = Sq; a.Sk = Sk; a.H = H; a.nsplit = nsplit; a.nprob = nprob;
+  a.opart = (float*)c->ar.alloc(nprob * nsplit * Sq * DH * (int64_t)sizeof(float));
+  a.mlpart = (float*)c->ar.alloc(nprob * nsplit * Sq * 2 * (int64_t)sizeof(float));
+  if (!c->dry) {
+    ProfScope ps(c, PROF_ATTN_FWD, 4.0 * (double)nprob * Sq * Sk * DH, (double)nprob * (2.0 * Sq + 2.0 * Sk) * DH * 2.0);
+    ps.tag(nseq, Sk, H, Sq);
+    const int lds = 2 * XCHUNK * ROWB + XCHUNK * 4;
+    xattn_fwd_kernel<<<(unsigned)(nprob * nsplit), 256, lds, c->stream>>>(a);
+    const int64_t nrows = nprob * Sq;
+    xattn_combine_kernel<<<(unsigned)((nrows + 3) / 4), 256, 0, c->stream>>>(a.opart, a.mlpart, nsplit, Sq, H, nrows, o, lse);
+    SPA_LAUNCH_CHECK(c);
+  }
+  c->ar.release(mk);  // stream-ordered: whatever reuses the space is launched behind the two kernels
+  return true;
+}
 
 constexpr int ATTN_MAX_S = 320;  // K^ and V of one head resident: 2 x 320 x 192 B = 120 KiB of the CU's 160 KiB
 
@@ -286,6 +484,7 @@ constexpr int ATTN_MAX_S = 320;  // K^ and V of one head resident: 2 x 320 x 192
 bool attn_fused_fwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const bf16_t* v, int64_t ldq, int64_t ldk, int64_t ldv,
                          const float* sq, const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, bf16_t* o,
                          float* lse, const int32_t* seq_off, int64_t total_rows) {
+  if (Dh == DH && Sq != Sk) return xattn_fwd(c, q, k, v, ldq, ldk, ldv, sq, sk, km, nseq, Sq, Sk, H, o, lse, seq_off);
   if (Dh != DH || Sq != Sk || Sk < 2 || Sk > ATTN_MAX_S) return false;
   if (ldq % 8 || ldk % 8 || ldv % 8 || !al16(q) || !al16(k) || !al16(v) || !al16(o)) return false;
   if (nseq * H > 0x7fffffffLL) return false;
@@ -340,6 +539,9 @@ struct AttnBwdArgs {
   int S, H; int64_t nprob;
   bf16_t *dq, *dk, *dv; float *dsq, *dsk;
   const int32_t* seq_off;  // as AttnArgs::seq_off
+  // cross attention (attn_bwd8_kernel<8, true>): S = query rows per sequence (<= 128); the Sk keys of a sequence are cut into nsplit chunks
+  // of 128, one workgroup pass per (sequence, head, chunk); dq^ (before the RMSNorm backward) leaves as fp32 partials per chunk
+  int Sk, nsplit; float* dqpart;  // [nprob][nsplit][S][96]
 #ifdef SPA3D_ABLATE  // tools/ablate_attn.py builds a separate diagnostic library with this; never defined for libspa3d_hip.so
   int ablate;          // 1: no tile work, 2: no staging (garbage operands), 4: no dq/dk/dv stores
 #endif
@@ -347,11 +549,13 @@ struct AttnBwdArgs {
 
 // (a) one 16-query tile against all keys.  qb / dob: this lane's query row as B-operand fragments (q^ normalised); mq, lq, dq_:
 // the row's (max, log-sum, delta); xraw: the raw q row in the accumulator layout (d = 16dt + 4fq + r) for the RMSNorm backward.
-template <int KT>
+// X (cross attention): the tile's dQ^ rows go out as fp32 partials (dqp: row 0 of the tile, 96 floats per row) -- the sum over key chunks and
+// the RMSNorm backward happen in xattn_dq_finish_kernel; xraw / wt / gtile / ds_acc are unused.
+template <int KT, bool X = false>
 __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, const float* kbias, const float* scq,
                                                const mfma16x8 (&qb)[3], const mfma16x8 (&dob)[3], float mq, float lq, float dq_,
                                                const u16x4 (&xraw)[6], bool valid, char* wt, bf16_t* gtile, int64_t ld_, int nrows,
-                                               float (&ds_acc)[6][4]) {
+                                               float (&ds_acc)[6][4], float* dqp = nullptr) {
   const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
   const float alpha = 0.10206207261596575f;  // 1/sqrt(96)
   mfma16x8 dsb[KT / 2];
@@ -399,6 +603,13 @@ __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, c
       dqa[dt] = MFMA16(__builtin_bit_cast(mfma16x8, u), dsb[s2], dqa[dt]);
     }
   });
+  if constexpr (X) {
+    if (fr < nrows) {
+#pragma unroll
+      for (int dt = 0; dt < 6; ++dt) *(f32x4*)(dqp + fr * DH + dt * 16 + fq * 4) = dqa[dt];
+    }
+    return;
+  }
   // RMSNorm backward for query fr: lane holds d = 16dt + 4fq + r
   float x[6][4]; float ss = 0.f;
 #pragma unroll
@@ -578,7 +789,9 @@ __device__ __forceinline__ void flush_scale_grads(const AttnBwdArgs& g, float* s
 
 // 8-wave form, four resident images: waves 0-3 take the query tiles (dQ) while waves 4-7 take the key tiles (dK, dV) of the same
 // problem: two waves per SIMD to overlap LDS/exp latency with the other's MFMAs, compute = max(a, b) instead of a + b.
-template <int KT>
+// X: cross attention -- a "problem" is (sequence, head, 128-key chunk): query-side rows (q, dO, O, lse: g.S per sequence) and key-side rows
+// (k, v: the chunk) come from different places, role (a) emits dq^ partials instead of dq (see bwd_query_tile).
+template <int KT, bool X = false>
 __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
   constexpr int S_pad = KT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -598,12 +811,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
   for (int t = tid; t < 2 * DH; t += 512) sscale[t] = t < DH ? g.sq[t] : g.sk[t - DH];
   __syncthreads();
   const int64_t nseq = g.nprob / g.H;
-  for (int64_t pi = blockIdx.x; pi < g.nprob; pi += gridDim.x) {
-    const int64_t prob = map_prob(pi, nseq, g.H);
+  const int64_t nwork = X ? g.nprob * g.nsplit : g.nprob;
+  for (int64_t pi = blockIdx.x; pi < nwork; pi += gridDim.x) {
+    const int64_t prob = X ? pi / g.nsplit : map_prob(pi, nseq, g.H);
+    const int sp = X ? (int)(pi - prob * g.nsplit) : 0;
     const int64_t seq = prob / g.H; const int h = (int)(prob - seq * g.H);
-    const int64_t row0 = g.seq_off ? (int64_t)g.seq_off[seq] : seq * g.S;
-    const int S = g.seq_off ? g.seq_off[seq + 1] - (int)row0 : g.S;
-    const int QT = (S + 15) / 16;
+    const int64_t row0 = X ? seq * g.S : g.seq_off ? (int64_t)g.seq_off[seq] : seq * g.S;   // first query-side row
+    const int S = (!X && g.seq_off) ? g.seq_off[seq + 1] - (int)row0 : g.S;               // query-side rows
+    const int64_t krow0 = X ? seq * g.Sk + (int64_t)sp * S_pad : row0;                   // first key-side row
+    const int Sk = X ? min(S_pad, g.Sk - sp * S_pad) : S;                                 // key-side rows
+    const int QT = (S + 15) / 16, QTk = (Sk + 15) / 16;
     constexpr int NP = (S_pad + 127) / 128;
     // all five matrices of the problem are requested before the first is used: one memory latency per problem
     RawRows<NP> rq, rk, rv, rd, ro;
@@ -611,8 +828,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
     if (!(g.ablate & 2)) {
 #endif
     rows_load<NP, 128>(rq, g.q + row0 * g.ldq + h * DH, g.ldq, S);
-    rows_load<NP, 128>(rk, g.k + row0 * g.ldk + h * DH, g.ldk, S);
-    rows_load<NP, 128>(rv, g.v + row0 * g.ldv + h * DH, g.ldv, S);
+    rows_load<NP, 128>(rk, g.k + krow0 * g.ldk + h * DH, g.ldk, Sk);
+    rows_load<NP, 128>(rv, g.v + krow0 * g.ldv + h * DH, g.ldv, Sk);
     rows_load<NP, 128>(rd, g.d_o + row0 * E + h * DH, E, S);
     rows_load<NP, 128>(ro, g.o + row0 * E + h * DH, E, S);
     __syncthreads();  // previous problem's LDS reads are done
@@ -625,11 +842,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
 #endif
     for (int t = tid; t < S_pad; t += 512) {
       float b = 0.f, m = 0.f, ll = __builtin_inff();  // padding query: P = exp(.. - inf) = 0
-      if (t >= S) b = -__builtin_inff();
-      else {
-        if (g.km && g.km[row0 + t] == 0.f) b = NEG_BIG;
-        m = g.lse[(row0 * g.H + (int64_t)h * S + t) * 2]; ll = g.lse[(row0 * g.H + (int64_t)h * S + t) * 2 + 1];
-      }
+      if (t >= Sk) b = -__builtin_inff();
+      else if (g.km && g.km[krow0 + t] == 0.f) b = NEG_BIG;
+      if (t < S) { m = g.lse[(row0 * g.H + (int64_t)h * S + t) * 2]; ll = g.lse[(row0 * g.H + (int64_t)h * S + t) * 2 + 1]; }
       kbias[t] = b; mrow[t] = m; lrow[t] = ll;
     }
     __syncthreads();
@@ -643,7 +858,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
         // raw q row of this lane's query for the RMSNorm backward: requested NOW so the HBM/L2 latency hides under the MFMAs
         int qrow = q0 + fr; const bool valid = qrow < S; if (!valid) qrow = S - 1;
         u16x4 xraw[6];
-        {
+        if constexpr (!X) {
           const bf16_t* xp = g.q + (row0 + qrow) * g.ldq + h * DH + fq * 4;
 #pragma unroll
           for (int dt = 0; dt < 6; ++dt) xraw[dt] = *(const u16x4*)(xp + dt * 16);
@@ -659,16 +874,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
 #else
         const int nrows_st = S - q0;
 #endif
-        bwd_query_tile<KT>(Ks, Vs, kbias, sscale, qb, dob, mrow[q0 + fr], lrow[q0 + fr], drow[q0 + fr], xraw, valid, wt,
-                           g.dq + (row0 + q0) * g.ldq + h * DH, g.ldq, nrows_st, ds_acc);
+        bwd_query_tile<KT, X>(Ks, Vs, kbias, sscale, qb, dob, mrow[q0 + fr], lrow[q0 + fr], drow[q0 + fr], xraw, valid, wt,
+                              g.dq + (row0 + q0) * g.ldq + h * DH, g.ldq, nrows_st, ds_acc,
+                              X ? g.dqpart + ((pi * g.S) + q0) * DH : nullptr);
       }
     } else {          // ------------------------------------------------------------------ (b) key tiles -> dk, dv
-      for (int kt = w; kt < QT; kt += 4) {  // real key tiles only (S_q == S_k)
+      for (int kt = w; kt < QTk; kt += 4) {  // real key tiles only
         const int k0 = kt * 16;
-        int krow = k0 + fr; const bool valid = krow < S; if (!valid) krow = S - 1;
+        int krow = k0 + fr; const bool valid = krow < Sk; if (!valid) krow = Sk - 1;
         u16x4 xraw[6];  // raw k row for the RMSNorm backward, requested before the MFMA work (see part (a))
         {
-          const bf16_t* xp = g.k + (row0 + krow) * g.ldk + h * DH + fq * 4;
+          const bf16_t* xp = g.k + (krow0 + krow) * g.ldk + h * DH + fq * 4;
 #pragma unroll
           for (int dt = 0; dt < 6; ++dt) xraw[dt] = *(const u16x4*)(xp + dt * 16);
         }
@@ -679,16 +895,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
           vb[s] = *(const mfma16x8*)(Vs + (k0 + fr) * ROWB + (s * 32 + fq * 8) * 2);
         }
 #ifdef SPA3D_ABLATE
-        const int nrows_st = (g.ablate & 4) ? 0 : S - k0;
+        const int nrows_st = (g.ablate & 4) ? 0 : Sk - k0;
 #else
-        const int nrows_st = S - k0;
+        const int nrows_st = Sk - k0;
 #endif
-        bwd_key_tile<KT>(Qs, dOs, mrow, lrow, drow, sscale + DH, kb, vb, kbias[k0 + fr], xraw, valid, wt, g.dk + (row0 + k0) * g.ldk + h * DH,
-                         g.ldk, g.dv + (row0 + k0) * g.ldv + h * DH, g.ldv, nrows_st, ds_acc);
+        bwd_key_tile<KT>(Qs, dOs, mrow, lrow, drow, sscale + DH, kb, vb, kbias[k0 + fr], xraw, valid, wt, g.dk + (krow0 + k0) * g.ldk + h * DH,
+                         g.ldk, g.dv + (krow0 + k0) * g.ldv + h * DH, g.ldv, nrows_st, ds_acc);
       }
     }
   }
-  flush_scale_grads<512>(g, sred, ds_acc, ds_acc, role == 0, role == 1);
+  flush_scale_grads<512>(g, sred, ds_acc, ds_acc, !X && role == 0, role == 1);
 }
 
 // split-pass form, two images: see the section header.  NW waves per workgroup (4: two workgroups per CU at S <= 192; 8: one).
@@ -861,6 +1077,36 @@ bool attn_fused_bwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const b
                          const float* sq, const float* sk, const float* km, int64_t nseq, int Sq, int Sk, int H, int Dh, const bf16_t* o,
                          const float* lse, const bf16_t* d_o, bf16_t* dq, bf16_t* dk, bf16_t* dv, float* dsq, float* dsk,
                          const int32_t* seq_off, int64_t total_rows) {
+  if (Dh == DH && Sq != Sk) {  // cross attention: chunked keys, see xattn_fwd_kernel
+    const int nsplit = (Sk + XCHUNK - 1) / XCHUNK;
+    const int64_t nprob = nseq * H;
+    if (seq_off || !o || !lse || Sq < 1 || Sq > XCHUNK || Sk < 1 || nprob * nsplit > 0x7fffffffLL) return false;
+    if (ldq % 8 || ldk % 8 || ldv % 8 || !al16(q) || !al16(k) || !al16(v) || !al16(o) || !al16(d_o) || !al16(dq) || !al16(dk) || !al16(dv) ||
+        !al16(sq) || !al16(sk))
+      return false;
+    const int64_t mk = c->ar.mark();
+    float* dqpart = (float*)c->ar.alloc(nprob * nsplit * Sq * DH * (int64_t)sizeof(float));
+    if (!c->dry) {
+      AttnBwdArgs a; a.q = q; a.k = k; a.v = v; a.o = o; a.d_o = d_o; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.sq = sq; a.sk = sk; a.km = km;
+      a.lse = lse; a.S = Sq; a.H = H; a.nprob = nprob; a.dq = dq; a.dk = dk; a.dv = dv; a.dsq = dsq; a.dsk = dsk; a.seq_off = nullptr;
+      a.Sk = Sk; a.nsplit = nsplit; a.dqpart = dqpart;
+#ifdef SPA3D_ABLATE
+      a.ablate = 0;
+#endif
+      ProfScope ps(c, PROF_ATTN_BWD, 14.0 * (double)nprob * Sq * Sk * DH, (double)nprob * (4.0 * Sq + 4.0 * Sk) * DH * 2.0);
+      ps.tag(nseq, Sk, H, Sq);
+      constexpr int KT = XCHUNK / 16;
+      const int lds4 = 4 * XCHUNK * ROWB + 4 * XCHUNK * 4 + 4 * DH * 4 + 8 * WTILE;
+      static bool attr_set = false;
+      if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd8_kernel<KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4); attr_set = true; }
+      attn_bwd8_kernel<KT, true><<<(unsigned)std::min<int64_t>(nprob * nsplit, 1024), 512, lds4, c->stream>>>(a);
+      const int64_t nrows = nprob * Sq;
+      xattn_dq_finish_kernel<<<(unsigned)std::min<int64_t>((nrows + 3) / 4, 512), 256, 0, c->stream>>>(dqpart, nsplit, Sq, H, nrows, q, ldq, sq, dq, dsq);
+      SPA_LAUNCH_CHECK(c);
+    }
+    c->ar.release(mk);
+    return true;
+  }
   if (Dh != DH || Sq != Sk || Sk < 2 || Sk > ATTN_MAX_S || !o || !lse) return false;
   if (ldq % 8 || ldk % 8 || ldv % 8 || !al16(q) || !al16(k) || !al16(v) || !al16(o) || !al16(d_o) || !al16(dq) || !al16(dk) || !al16(dv) ||
       !al16(sq) || !al16(sk))
@@ -868,6 +1114,7 @@ bool attn_fused_bwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const b
   if (c->dry) return true;
   AttnBwdArgs a; a.q = q; a.k = k; a.v = v; a.o = o; a.d_o = d_o; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.sq = sq; a.sk = sk; a.km = km;
   a.lse = lse; a.S = Sk; a.H = H; a.nprob = nseq * H; a.dq = dq; a.dk = dk; a.dv = dv; a.dsq = dsq; a.dsk = dsk; a.seq_off = seq_off;
+  a.Sk = Sk; a.nsplit = 1; a.dqpart = nullptr;
   const double rows = total_rows > 0 ? (double)total_rows : (double)nseq * Sk;
 #ifdef SPA3D_ABLATE
   { const char* e = getenv("SPA3D_ABLATE"); a.ablate = e ? atoi(e) : 0; }

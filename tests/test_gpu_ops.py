@@ -13,7 +13,7 @@ from util import O, max_abs, rel_err
 
 pytestmark = pytest.mark.gpu
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 
 
 @pytest.fixture(scope='module')
@@ -31,7 +31,7 @@ def _ws(nbytes=256 << 20):
 
 
 def _dt(dtype):
-  return torch.float32 if dtype == F32 else torch.bfloat16
+  return {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[dtype]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -356,6 +356,65 @@ def test_attention_fused_fwd_bwd(lib, monkeypatch, nseq, S, H, masked, bwd_mode)
           rel_err(dsq, sqr.grad), rel_err(dsk, skr.grad)]
   print('fused attention bwd rel errs dq dk dv dsq dsk', errs)
   assert max(errs) < 3e-2
+
+
+@pytest.mark.parametrize('dtype', [BF16, F16])
+@pytest.mark.parametrize('nseq,Sq,Sk,H,masked', [(3, 128, 2048, 8, False), (2, 128, 300, 8, True), (2, 100, 129, 8, True), (5, 16, 128, 2, False),
+                                                 (1, 128, 8192, 8, False), (2, 37, 1000, 4, True)])
+def test_attention_fused_cross(lib, dtype, nseq, Sq, Sk, H, masked):
+  """Fused cross attention (impl=2, Sq != Sk: the 128 latents against the N track tokens, track_autoencoder_3d.py:95-100,201) vs the fp64
+  oracle: keys in chunks of 128 with a split-softmax merge, dq^ partials per chunk summed before the RMSNorm backward.  Sk = 300 / 129 /
+  1000: ragged last chunk (129: a one-key chunk); Sq = 100 / 37 / 16: partial query tiles; a fully masked first sequence and chunks whose
+  keys are all masked exercise the finfo.min semantics across the merge."""
+  Dh, E = 96, H * 96
+  dt = _dt(dtype)
+  g = torch.Generator().manual_seed(33)
+  q = torch.randn(nseq, Sq, E, generator=g).to(dt)
+  kv = torch.randn(nseq, Sk, 2 * E, generator=g).to(dt)
+  sq = 1 + 0.2 * torch.randn(Dh, generator=g)
+  sk = 1 + 0.2 * torch.randn(Dh, generator=g)
+  km = None
+  if masked:
+    km = (torch.rand(nseq, Sk, generator=g) < 0.7).float()
+    km[0, :] = 0.0            # every key masked: uniform attention over ALL keys
+    if nseq > 1:
+      km[1, :min(Sk // 2, 256)] = 0.0  # whole chunks masked, others not
+      km[1, -1] = 1.0
+  qd, kvd, sqd, skd = q.cuda(), kv.cuda(), sq.cuda(), sk.cuda()
+  kmd = km.cuda() if masked else None
+  o = torch.full((nseq, Sq, E), float('nan'), device='cuda', dtype=dt)
+  lse = torch.zeros(nseq, H, Sq, 2, device='cuda')
+  ws = _ws(512 << 20)
+  rc = lib.spa3d_op_attention(qd.data_ptr(), kvd[..., :E].data_ptr(), kvd[..., E:].data_ptr(), E, 2 * E, 2 * E, sqd.data_ptr(), skd.data_ptr(),
+                              kmd.data_ptr() if masked else None, nseq, Sq, Sk, H, Dh, o.data_ptr(), lse.data_ptr(), dtype, 2, ws.data_ptr(),
+                              ws.numel(), _s())
+  assert rc == 0
+  qr = q.double().requires_grad_(True)
+  kr = kv[..., :E].double().contiguous().requires_grad_(True)
+  vr = kv[..., E:].double().contiguous().requires_grad_(True)
+  sqr, skr = sq.double().requires_grad_(True), sk.double().requires_grad_(True)
+  ref = _attn_ref(qr, kr, vr, sqr, skr, km, H, Dh)
+  assert not torch.isnan(o.float()).any()
+  e = rel_err(o.float(), ref.detach())
+  print('fused cross attention fwd rel err', e)
+  assert e < (2e-2 if dtype == BF16 else 4e-3)
+  d_o = torch.randn(nseq, Sq, E, generator=g).to(dt)
+  ref.backward(d_o.double())
+  dod = d_o.cuda()
+  dq = torch.full((nseq, Sq, E), float('nan'), device='cuda', dtype=dt)
+  dkv = torch.full((nseq, Sk, 2 * E), float('nan'), device='cuda', dtype=dt)
+  dsq = torch.zeros(Dh, device='cuda')
+  dsk = torch.zeros(Dh, device='cuda')
+  rc = lib.spa3d_op_attention_bwd(qd.data_ptr(), kvd[..., :E].data_ptr(), kvd[..., E:].data_ptr(), E, 2 * E, 2 * E, sqd.data_ptr(), skd.data_ptr(),
+                                  kmd.data_ptr() if masked else None, nseq, Sq, Sk, H, Dh, o.data_ptr(), lse.data_ptr(), dod.data_ptr(),
+                                  dq.data_ptr(), dkv[..., :E].data_ptr(), dkv[..., E:].data_ptr(), dsq.data_ptr(), dsk.data_ptr(), dtype, 2,
+                                  ws.data_ptr(), ws.numel(), _s())
+  assert rc == 0
+  assert not torch.isnan(dq.float()).any() and not torch.isnan(dkv.float()).any()
+  errs = [rel_err(dq.float(), qr.grad), rel_err(dkv[..., :E].float(), kr.grad), rel_err(dkv[..., E:].float(), vr.grad), rel_err(dsq, sqr.grad),
+          rel_err(dsk, skr.grad)]
+  print('fused cross attention bwd rel errs dq dk dv dsq dsk', errs)
+  assert max(errs) < (3e-2 if dtype == BF16 else 6e-3)
 
 
 @pytest.mark.parametrize('M,N,K,act,res,bias', [(1000, 384, 256, 0, False, True), (4133, 2304, 384, 0, False, False), (2050, 384, 1536, 0, True, True)])
