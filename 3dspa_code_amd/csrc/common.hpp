@@ -144,6 +144,7 @@ struct spa3d_ctx {
   int hip_err = 0;
   int gemm_impl = 0;  // 0 auto, 1 generic only
   int attn_impl = 0;
+  int ro_share = 1;       // readout block 1: LayerNorm / QKV once per distinct (sample, query frame) instead of per query (16-bit modes); SPA3D_RO_SHARE=0 disables
   int prune = 1;          // drop masked frame tokens from the track encoder (3DSPA model, fused 16-bit attention path); SPA3D_PRUNE=0 disables
   float loss_scale = 1.f;  // the 16-bit backward runs at loss x scale, parameter gradients are scaled back at the end: 1 = off (bf16 / fp32),
                            // > 0 a fixed scale, < 0 automatic with |loss_scale| the target head-gradient magnitude (fp16 mode: -16)
@@ -263,6 +264,14 @@ void k_query_embed1(spa3d_ctx*, const float* qp, int64_t nq, int nf, float track
                     int NC = 3);
 template <typename T> void k_assemble_readout(spa3d_ctx*, const T* qtok, const T* lat, const int32_t* qframe, int64_t B, int Q, int L, int Cl,
                                               int D, T* seq);
+// shared latent rows of the readout stack's first block (kernels.hip "Shared latent rows"; model.hip Share)
+int64_t k_share_plan(spa3d_ctx*, const int32_t* qframe, int64_t B, int Q, int32_t* slot, int32_t* slot_b, int32_t* slot_f, int32_t* slot_q0, int32_t* scratch);
+template <typename T> void k_share_assemble(spa3d_ctx*, const T* qtok, const T* lat, const int32_t* slot_b, const int32_t* slot_f, int64_t nslot, int64_t BQ,
+                                            int L, int Cl, int D, T* xU);
+template <typename T> void k_share_expand(spa3d_ctx*, const T* srcU, const int32_t* slot, const int32_t* slot_q0, int64_t nslot, int64_t nseq, int S, int d,
+                                          const T* add, T* dst);
+template <typename T> void k_share_reduce(spa3d_ctx*, const T* src, const int32_t* slot, const int32_t* slot_b, int64_t nslot, int64_t nseq, int Q, int S, int d,
+                                          T* dstU);
 template <typename T> void k_assemble_readout_bwd(spa3d_ctx*, const T* dseq, const int32_t* qframe, int64_t B, int Q, int L, int Cl, int D,
                                                   T* dqtok, float* dlat);
 void k_loss_fwd(spa3d_ctx*, const float* head, int64_t nq, int T_, const float* tgt, const float* tvis, float* tracks, float* vlog,

@@ -970,6 +970,180 @@ template <typename T> void k_rows_idx(spa3d_ctx* c, int mode, const T* src, cons
   SPA_LAUNCH_CHECK(c);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Shared latent rows of the readout stack's first block (track_autoencoder_3d.py:276-285, 235-246): token n >= 1 of the sequence of
+// query (b, q) is [lat[b][n] | lat[b][n][5 t_q : 5 t_q + 128]] -- a function of (b, n, t_q) only, so every query of a sample with the same
+// frame t_q carries the same 128 latent rows into the block's LayerNorm and QKV projection.  A "slot" is a distinct (sample, frame)
+// pair; the block runs LN1 / QKV (and their backward) once per slot and expands / reduces through the slot index (model.hip, Share).
+// ---------------------------------------------------------------------------------------------
+// per sample: slot_local[q] = rank of q's frame among the distinct frames of the sample (order of first occurrence); nslot_b[b] = their number
+__global__ __launch_bounds__(256) void share_plan_kernel(const int32_t* __restrict__ qframe, int Q, int32_t* __restrict__ slot, int32_t* __restrict__ nslot_b,
+                                                         int32_t* __restrict__ first_q) {
+  extern __shared__ int32_t sh[];  // [Q] first occurrence of q's frame, then its rank
+  const int b = blockIdx.x;
+  const int32_t* fr = qframe + (int64_t)b * Q;
+  for (int q = threadIdx.x; q < Q; q += 256) {
+    const int32_t f = fr[q];
+    int first = q;
+    for (int p = 0; p < q; ++p) if (fr[p] == f) { first = p; break; }
+    sh[q] = first;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int n = 0;
+    for (int q = 0; q < Q; ++q) {
+      if (sh[q] == q) { first_q[(int64_t)b * Q + n] = q; sh[q] = -(n + 1); ++n; }  // firsts carry -(rank + 1)
+    }
+    nslot_b[b] = n;
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < Q; q += 256) {
+    const int32_t v = sh[q];
+    slot[(int64_t)b * Q + q] = v < 0 ? -v - 1 : -sh[v] - 1;  // local rank; made global by share_plan_finish_kernel
+  }
+}
+// prefix over samples: slot -> global slot index; slot_b / slot_f / slot_q0: sample, frame and first member sequence of every slot; total[0] = number of slots
+__global__ __launch_bounds__(256) void share_plan_finish_kernel(const int32_t* __restrict__ qframe, int B, int Q, int32_t* __restrict__ slot,
+                                                                const int32_t* __restrict__ nslot_b, const int32_t* __restrict__ first_q,
+                                                                int32_t* __restrict__ slot_b, int32_t* __restrict__ slot_f, int32_t* __restrict__ slot_q0,
+                                                                int32_t* __restrict__ total) {
+  __shared__ int32_t off[1025];
+  if (threadIdx.x == 0) { int a = 0; for (int b = 0; b < B; ++b) { off[b] = a; a += nslot_b[b]; } off[B] = a; total[0] = a; }
+  __syncthreads();
+  for (int64_t i = threadIdx.x; i < (int64_t)B * Q; i += 256) {
+    const int b = (int)(i / Q), j = (int)(i - (int64_t)b * Q);
+    slot[i] += off[b];
+    if (j < nslot_b[b]) { slot_b[off[b] + j] = b; slot_f[off[b] + j] = qframe[(int64_t)b * Q + first_q[i]]; slot_q0[off[b] + j] = b * Q + first_q[i]; }
+  }
+}
+// returns the number of slots (ONE stream synchronisation); B * Q (every query its own slot) when dry
+int64_t k_share_plan(spa3d_ctx* c, const int32_t* qframe, int64_t B, int Q, int32_t* slot, int32_t* slot_b, int32_t* slot_f, int32_t* slot_q0,
+                     int32_t* scratch /*[B*Q + B + 1]*/) {
+  if (c->dry) return B * Q;
+  if (B > 1024 || Q > 12288) { if (!c->hip_err) { c->hip_err = -6; c->err = "share plan: at most 1024 samples per chunk and 12288 queries"; } return B * Q; }
+  int32_t* first_q = scratch; int32_t* nslot_b = scratch + B * Q; int32_t* total = nslot_b + B;
+  share_plan_kernel<<<(unsigned)B, 256, Q * sizeof(int32_t), c->stream>>>(qframe, Q, slot, nslot_b, first_q); SPA_LAUNCH_CHECK(c);
+  share_plan_finish_kernel<<<1, 256, 0, c->stream>>>(qframe, (int)B, Q, slot, nslot_b, first_q, slot_b, slot_f, slot_q0, total); SPA_LAUNCH_CHECK(c);
+  int32_t n = 0;
+  if (hipMemcpyAsync(&n, total, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+    if (!c->hip_err) { c->hip_err = -4; c->err = "share plan: reading the slot count failed"; }
+    return B * Q;
+  }
+  return n;
+}
+// xU = [nslot * L latent rows | B*Q query-token rows]: the distinct rows of the readout sequences (assemble_vec_kernel's values)
+template <typename T>
+__global__ void share_assemble_kernel(const T* __restrict__ qtok, const T* __restrict__ lat, const int32_t* __restrict__ slot_b,
+                                      const int32_t* __restrict__ slot_f, int64_t nslot, int64_t BQ, int L, int Cl, int D, T* __restrict__ xU) {
+  constexpr int NV = VecOf<T>::N;
+  const int cpr = D / NV;
+  const int64_t nlat = nslot * L, tot = (nlat + BQ) * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / cpr; const int j = (int)(i - row * cpr) * NV;
+    float v[NV];
+    if (row >= nlat) load_vec<T, NV>(qtok + (row - nlat) * D + j, v);
+    else {
+      const int64_t s_ = row / L; const int n = (int)(row - s_ * L);
+      const T* lr = lat + ((int64_t)slot_b[s_] * L + n) * Cl;
+      if (j < Cl) load_vec<T, NV>(lr + j, v);
+      else {
+        const int base = j - Cl + 5 * slot_f[s_];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) { const int cc = base + e; v[e] = (cc >= 0 && cc < Cl) ? ld(lr + cc) : 0.f; }
+      }
+    }
+    store_vec<T, NV>(xU + row * D + j, v);
+  }
+}
+template <typename T>
+void k_share_assemble(spa3d_ctx* c, const T* qtok, const T* lat, const int32_t* slot_b, const int32_t* slot_f, int64_t nslot, int64_t BQ, int L, int Cl,
+                      int D, T* xU) {
+  if (c->dry || BQ == 0) return;
+  constexpr int NV = VecOf<T>::N;
+  if (D % NV || Cl % NV) { if (!c->hip_err) { c->hip_err = -5; c->err = "share assemble: widths must be multiples of 16 bytes"; } return; }
+  share_assemble_kernel<T><<<GRID1D((nslot * L + BQ) * (D / NV), 256), 256, 0, c->stream>>>(qtok, lat, slot_b, slot_f, nslot, BQ, L, Cl, D, xU);
+  SPA_LAUNCH_CHECK(c);
+}
+// dense rows from slot rows.  Forward (add == nullptr): dst[(seq, tkn)] = src[tkn == 0 ? nslot*L + seq : slot[seq]*L + tkn - 1], a gather.
+// Backward (add != nullptr): the slot row holds the SUM over the slot's member sequences (the LayerNorm backward is linear in its incoming
+// gradient), so it is added to ONE member, the slot's first sequence slot_q0 -- every consumer downstream sums over the queries of a
+// sample with the members' common frame (k_assemble_readout_bwd) --, and dst = add elsewhere.
+template <typename T, bool ADD>
+__global__ void share_expand_kernel(const T* __restrict__ src, const int32_t* __restrict__ slot, const int32_t* __restrict__ slot_q0, int64_t nslot,
+                                    int64_t nseq, int S, int d, const T* add, T* dst) {
+  constexpr int NV = VecOf<T>::N;
+  const int cpr = d / NV, L = S - 1;
+  const int64_t tot = nseq * S * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / cpr; const int ch = (int)(i - row * cpr);
+    const int64_t seq = row / S; const int tkn = (int)(row - seq * S);
+    const int32_t sl = slot[seq];
+    const int64_t sr = tkn == 0 ? nslot * L + seq : (int64_t)sl * L + tkn - 1;
+    if constexpr (ADD) {
+      float b[NV];
+      load_vec<T, NV>(add + row * d + ch * NV, b);
+      if (tkn == 0 || slot_q0[sl] == (int32_t)seq) {
+        float a[NV];
+        load_vec<T, NV>(src + sr * d + ch * NV, a);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) b[j] += a[j];
+      }
+      store_vec<T, NV>(dst + row * d + ch * NV, b);
+    } else {
+      *(uint4*)(dst + row * d + ch * NV) = *(const uint4*)(src + sr * d + ch * NV);
+    }
+  }
+}
+template <typename T>
+void k_share_expand(spa3d_ctx* c, const T* src, const int32_t* slot, const int32_t* slot_q0, int64_t nslot, int64_t nseq, int S, int d, const T* add, T* dst) {
+  if (c->dry || nseq == 0) return;
+  constexpr int NV = VecOf<T>::N;
+  if (d % NV) { if (!c->hip_err) { c->hip_err = -5; c->err = "share expand: row width must be a multiple of 16 bytes"; } return; }
+  const dim3 g = GRID1D(nseq * S * (d / NV), 256);
+  if (add) share_expand_kernel<T, true><<<g, 256, 0, c->stream>>>(src, slot, slot_q0, nslot, nseq, S, d, add, dst);
+  else share_expand_kernel<T, false><<<g, 256, 0, c->stream>>>(src, slot, slot_q0, nslot, nseq, S, d, nullptr, dst);
+  SPA_LAUNCH_CHECK(c);
+}
+// slot rows from dense rows (the transpose of the expansion): dstU[(s, n)] = sum over the sequences of slot s of src[(seq, 1 + n)] (fp32 sums);
+// dstU[nslot*L + seq] = src[(seq, 0)].  One workgroup per slot: the member list is built once in LDS, then rows are walked 16 B per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void share_reduce_kernel(const T* __restrict__ src, const int32_t* __restrict__ slot, const int32_t* __restrict__ slot_b,
+                                                           int64_t nslot, int Q, int S, int d, T* __restrict__ dstU) {
+  constexpr int NV = VecOf<T>::N;
+  extern __shared__ int32_t members[];  // [Q] + count
+  __shared__ int32_t nmem;
+  const int64_t s_ = blockIdx.x; const int L = S - 1, cpr = d / NV;
+  const int b = slot_b[s_];
+  if (threadIdx.x == 0) nmem = 0;
+  __syncthreads();
+  for (int q = threadIdx.x; q < Q; q += 256)
+    if (slot[(int64_t)b * Q + q] == (int32_t)s_) members[atomicAdd(&nmem, 1)] = q;
+  __syncthreads();
+  const int nm = nmem;
+  for (int i = threadIdx.x; i < L * cpr; i += 256) {
+    const int n = i / cpr, ch = i - n * cpr;
+    float acc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[j] = 0.f;
+    for (int m = 0; m < nm; ++m) {
+      float v[NV];
+      load_vec<T, NV>(src + (((int64_t)b * Q + members[m]) * S + 1 + n) * d + ch * NV, v);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) acc[j] += v[j];
+    }
+    store_vec<T, NV>(dstU + (s_ * L + n) * d + ch * NV, acc);
+  }
+}
+template <typename T>
+void k_share_reduce(spa3d_ctx* c, const T* src, const int32_t* slot, const int32_t* slot_b, int64_t nslot, int64_t nseq, int Q, int S, int d, T* dstU) {
+  if (c->dry || nseq == 0) return;
+  constexpr int NV = VecOf<T>::N;
+  if (d % NV) { if (!c->hip_err) { c->hip_err = -5; c->err = "share reduce: row width must be a multiple of 16 bytes"; } return; }
+  if (nslot > 0) share_reduce_kernel<T><<<(unsigned)nslot, 256, Q * sizeof(int32_t), c->stream>>>(src, slot, slot_b, nslot, Q, S, d, dstU);
+  SPA_LAUNCH_CHECK(c);
+  k_gather_rows<T>(c, src, S, dstU + nslot * (S - 1) * d, nseq, d);  // rows 0: one per sequence
+}
+
 // copy rows 1..S-1 of each sequence into a compact [nseq*(S-1)][d] buffer (drop the readout row)
 template <typename T>
 __global__ void compact_tokens_kernel(const T* __restrict__ tok, T* __restrict__ dst, int64_t nseq, int S, int d) {
@@ -1537,6 +1711,9 @@ void k_uniform_noise(spa3d_ctx* c, float* out, int64_t n, uint32_t k0, uint32_t 
   template bool k_rank_fwd<T>(spa3d_ctx*, const T*, const T*, const float*, T*, int64_t, int, int, int64_t, int, int);                \
   template bool k_rank_bwd<T>(spa3d_ctx*, const T*, const T*, int64_t, int, int, int64_t, int, int, float*, float*);                                              \
   template void k_assemble_readout<T>(spa3d_ctx*, const T*, const T*, const int32_t*, int64_t, int, int, int, int, T*);                \
+  template void k_share_assemble<T>(spa3d_ctx*, const T*, const T*, const int32_t*, const int32_t*, int64_t, int64_t, int, int, int, T*);   \
+  template void k_share_expand<T>(spa3d_ctx*, const T*, const int32_t*, const int32_t*, int64_t, int64_t, int, int, const T*, T*);    \
+  template void k_share_reduce<T>(spa3d_ctx*, const T*, const int32_t*, const int32_t*, int64_t, int64_t, int, int, int, T*);         \
   template void k_assemble_readout_bwd<T>(spa3d_ctx*, const T*, const int32_t*, int64_t, int, int, int, int, T*, float*);              \
   template void k_loss_bwd<T>(spa3d_ctx*, const float*, int64_t, int, const float*, const float*, const float*, float, float, T*, int, const float*);
 INST(float)

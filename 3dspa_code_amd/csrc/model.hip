@@ -56,7 +56,20 @@ template <typename T> struct XfW { std::vector<BlockW<T>> blocks; const float* n
 template <typename T> struct BlockStash {
   T *x, *nq, *qkv, *o, *a, *na, *hpre, *h, *cq = nullptr, *ckv = nullptr, *co = nullptr;
   float *st1, *st2, *lse = nullptr, *clse = nullptr;
+  bool shared = false;  // Share mode: x / nq / st1 hold the SLOT rows (xU, LN1(xU) and its statistics), not the dense ones
 };
+
+// Readout block 1 (track_autoencoder_3d.py:276-285): rows 1.. of the sequence of query (b, q) depend on (b, query frame) only, so LayerNorm 1 and
+// the QKV projection (forward, dW, dX, LN backward) run once per "slot" = distinct (sample, frame) pair and are expanded to / reduced
+// from the per-query rows through the slot index (kernels.hip "Shared latent rows"); the block's dx carries a slot's LN-backward term on
+// the slot's first sequence only (consumers sum over the queries of a sample).  xU = [nslot * (S-1) latent rows | one row 0 per
+// sequence].  Same values as the dense computation up to summation order (dqkv rows of a slot are pre-summed in fp32).
+template <typename T> struct Share {
+  const int32_t *slot = nullptr, *slot_b = nullptr, *slot_q0 = nullptr; int64_t nslot = 0; int Q = 0; const T* xU = nullptr;
+  bool probe = false;  // workspace-sizing pass: run the dense path (the larger stash) and add the Share backward's transients on top
+  int64_t rows(int64_t nseq, int S) const { return nslot * (S - 1) + nseq; }
+};
+constexpr double SHARE_MAX_FRAC = 0.45;  // Share is used when slots <= 45 % of the queries (above, its stash would exceed the dense one)
 
 // Ragged (token-pruned) sequences of the track encoder: compact row offsets [nseq + 1] and the exact kept-row count; off == nullptr: dense.
 // NT GEMMs run on the row count rounded up to 8 (the persistent kernels want M % 8 == 0; rows are independent there and every compact
@@ -203,13 +216,27 @@ template <typename T> struct Net {
 
   // ------------------------------------------------------------------ ImprovedTransformerBlock (attention.py:67-108)
   void block_fwd(const BlockW<T>& w, const T* x, T* y, int64_t nseq, int S, const float* km, const T* kv, int Skv, BlockStash<T>* st,
-                 const Rag& rg = Rag()) {
+                 const Rag& rg = Rag(), const Share<T>* sh = nullptr) {
     const int64_t M = rg.off ? rg.rows : nseq * S, Mg = rg.off ? (M + 7) & ~int64_t(7) : M; const int d = w.d;  // Mg: NT-GEMM rows (see Rag)
     int64_t mk = c->ar.mark();
-    T* nq = alloc<T>(Mg * d); float* st1 = alloc<float>(M * 2);
-    k_layernorm<T>(c, x, w.norm_q, nq, st1, M, d);                                      // :76-78
-    T* qkv = alloc<T>(Mg * 3 * E);
-    lin_fwd(w.qkv, nq, qkv, Mg);                                                         // :154-173
+    T *nq, *qkv; float* st1;
+    if (sh && sh->probe) sh = nullptr;
+    if (sh) {  // LN1 + QKV once per slot row, then expanded to the per-query rows the attention kernel reads
+      const int64_t MU = sh->rows(nseq, S), MUg = (MU + 7) & ~int64_t(7);
+      nq = alloc<T>(MUg * d); st1 = alloc<float>(MU * 2);
+      k_layernorm<T>(c, sh->xU, w.norm_q, nq, st1, MU, d);
+      qkv = alloc<T>(Mg * 3 * E);
+      const int64_t mk2 = c->ar.mark();
+      T* qkvU = alloc<T>(MUg * 3 * E);
+      lin_fwd(w.qkv, nq, qkvU, MUg);
+      k_share_expand<T>(c, qkvU, sh->slot, sh->slot_q0, sh->nslot, nseq, S, 3 * E, nullptr, qkv);
+      c->ar.release(mk2);
+    } else {
+      nq = alloc<T>(Mg * d); st1 = alloc<float>(M * 2);
+      k_layernorm<T>(c, x, w.norm_q, nq, st1, M, d);                                    // :76-78
+      qkv = alloc<T>(Mg * 3 * E);
+      lin_fwd(w.qkv, nq, qkv, Mg);                                                       // :154-173
+    }
     T* o = alloc<T>(Mg * E); float* lse = alloc<float>(M * H * 2);
     attn_fwd(qkv, qkv + E, qkv + 2 * E, 3 * E, 3 * E, 3 * E, w.sq, w.sk, km, nseq, S, S, o, lse, rg);  // :166-175
     T* a = alloc<T>(Mg * d);
@@ -227,13 +254,13 @@ template <typename T> struct Net {
     T* hpre = alloc<T>(Mg * w.mlp); T* h = alloc<T>(Mg * w.mlp);
     lin_fwd(w.mlp_in, na, h, Mg, EPI_GELU, nullptr, 0, 0, 0, 0, 0, 0, hpre);             // :106  h = gelu(hpre), both kept for the backward
     lin_fwd(w.mlp_out, h, y, Mg, EPI_NONE, a);                                           // :107-108
-    if (st) { st->x = const_cast<T*>(x); st->nq = nq; st->qkv = qkv; st->o = o; st->a = a; st->na = na; st->hpre = hpre; st->h = h;
-              st->st1 = st1; st->st2 = st2; st->cq = cq; st->ckv = ckv; st->co = co; st->lse = lse; st->clse = clse; }
+    if (st) { st->x = const_cast<T*>(sh ? sh->xU : x); st->nq = nq; st->qkv = qkv; st->o = o; st->a = a; st->na = na; st->hpre = hpre; st->h = h;
+              st->st1 = st1; st->st2 = st2; st->cq = cq; st->ckv = ckv; st->co = co; st->lse = lse; st->clse = clse; st->shared = sh != nullptr; }
     else c->ar.release(mk);
   }
   // dy -> dx (dx may alias dy); dkv accumulated (T) if cross
   void block_bwd(const BlockW<T>& w, const BlockStash<T>& s, const T* dy, T* dx, int64_t nseq, int S, const float* km, const T* kv,
-                 int Skv, T* dkv, const Rag& rg = Rag()) {
+                 int Skv, T* dkv, const Rag& rg = Rag(), const Share<T>* sh = nullptr) {
     const int64_t M = rg.off ? rg.rows : nseq * S, Mg = rg.off ? (M + 7) & ~int64_t(7) : M; const int d = w.d;
     int64_t mk = c->ar.mark();
     lin_bwd_w(w.mlp_out, s.h, dy, M);
@@ -252,6 +279,25 @@ template <typename T> struct Net {
     T* dqkv = alloc<T>(Mg * 3 * E);
     attn_bwd(s.qkv, s.qkv + E, s.qkv + 2 * E, 3 * E, 3 * E, 3 * E, w.sq, w.sk, km, nseq, S, S, s.o, s.lse, d_o, dqkv, dqkv + E,
              dqkv + 2 * E, w.g_sq, w.g_sk, rg);
+    if (sh && sh->probe) {  // sizing pass: the Share branch's transients at its largest admissible slot count, then the dense path
+      const int64_t MUg = (sh->rows(nseq, S) + 7) & ~int64_t(7), mk2 = c->ar.mark();
+      (void)alloc<T>(MUg * 3 * E); (void)alloc<T>(MUg * d); (void)alloc<T>(MUg * d);
+      c->ar.release(mk2);
+      sh = nullptr;
+    }
+    if (sh) {  // slot rows: dqkv pre-summed per slot, then dW / dX / LN1 backward on the slot rows and dx = da + expansion
+      const int64_t MU = sh->rows(nseq, S), MUg = (MU + 7) & ~int64_t(7);
+      T* dqkvU = alloc<T>(MUg * 3 * E);
+      k_share_reduce<T>(c, dqkv, sh->slot, sh->slot_b, sh->nslot, nseq, sh->Q, S, 3 * E, dqkvU);
+      lin_bwd_w(w.qkv, s.nq, dqkvU, MU);
+      T* dnU = alloc<T>(MUg * d);
+      lin_bwd_x(w.qkv, dqkvU, dnU, MUg);
+      T* dxU = alloc<T>(MU * d);
+      k_layernorm_bwd<T>(c, s.x, w.norm_q, s.st1, dnU, dxU, w.g_norm_q, MU, d, nullptr);
+      k_share_expand<T>(c, dxU, sh->slot, sh->slot_q0, sh->nslot, nseq, S, d, da, dx);
+      c->ar.release(mk);
+      return;
+    }
     lin_bwd_w(w.qkv, s.nq, dqkv, M);
     lin_bwd_x(w.qkv, dqkv, dnq, Mg);
     if (w.cross) {
@@ -355,7 +401,7 @@ template <typename T> struct Net {
     T* lat_in; std::vector<BlockStash<T>> t2l_st; T* t2l_last; float* st_t2l; T* t2l_n; float* latents;  // [Bc,L,Ld] f32
     // decode
     float* clipmask; float* lat_q; T* lat_qT; T* dec_in; std::vector<BlockStash<T>> dec_st; T* dec_last; float* st_dec; T* latd;
-    float* feat; int32_t* qframe; T* sin2; T* qtok; T* seq0; std::vector<BlockStash<T>> ro_st; T* ro_last; T* q0; float* st_q0; T* q0n;
+    float* feat; int32_t* qframe; T* sin2; T* qtok; T* seq0; Share<T> ro_sh; bool ro_share = false; std::vector<BlockStash<T>> ro_st; T* ro_last; T* q0; float* st_q0; T* q0n;
     float* head;
   };
 
@@ -479,11 +525,28 @@ template <typename T> struct Net {
     x = k.seq0;
     const int nro = (int)ro.blocks.size();
     k.ro_st.resize(nro);
+    // first block: LN1 / QKV once per distinct (sample, query frame) -- see Share.  One stream sync reads the slot count.
+    k.ro_sh = Share<T>(); k.ro_share = false;
+    if (sizeof(T) == 2 && c->ro_share && nro >= 2 && dd % 8 == 0 && Cl % 8 == 0 && k.Q >= 8) {
+      int32_t* slot = alloc<int32_t>(nq); int32_t* slot_b = alloc<int32_t>(nq); int32_t* slot_f = alloc<int32_t>(nq);
+      int32_t* slot_q0 = alloc<int32_t>(nq); int32_t* scratch = alloc<int32_t>(nq + k.Bc + 1);
+      Share<T>& sh = k.ro_sh;
+      sh.slot = slot; sh.slot_b = slot_b; sh.slot_q0 = slot_q0; sh.Q = k.Q;
+      if (c->dry) { sh.nslot = (int64_t)(SHARE_MAX_FRAC * (double)nq); sh.probe = true; k.ro_share = true; }
+      else {
+        sh.nslot = k_share_plan(c, k.qframe, k.Bc, k.Q, slot, slot_b, slot_f, slot_q0, scratch);
+        if ((double)sh.nslot <= SHARE_MAX_FRAC * (double)nq) {
+          T* xU = alloc<T>(((sh.rows(nq, S) + 7) & ~int64_t(7)) * dd);
+          k_share_assemble<T>(c, k.qtok, k.latd, slot_b, slot_f, sh.nslot, nq, L, Cl, dd, xU);
+          sh.xU = xU; k.ro_share = true;
+        }
+      }
+    }
     T* pp[2] = {nullptr, nullptr};
     if (!train && nro > 1) { pp[0] = alloc<T>(nq * S * dd); if (nro > 2) pp[1] = alloc<T>(nq * S * dd); }
     for (int i = 0; i + 1 < nro; ++i) {
       T* y = train ? alloc<T>(nq * S * dd) : pp[i & 1];
-      block_fwd(ro.blocks[i], x, y, nq, S, nullptr, nullptr, 0, train ? &k.ro_st[i] : nullptr);
+      block_fwd(ro.blocks[i], x, y, nq, S, nullptr, nullptr, 0, train ? &k.ro_st[i] : nullptr, Rag(), (i == 0 && k.ro_share) ? &k.ro_sh : nullptr);
       x = y;
     }
     k.ro_last = const_cast<T*>(x);
@@ -518,7 +581,7 @@ template <typename T> struct Net {
       const int nro = (int)ro.blocks.size();
       block_bwd_last(ro.blocks[nro - 1], k.ro_lst, dq0, dseq, nq, S, nullptr);
       for (int i = nro - 2; i >= 0; --i)
-        block_bwd(ro.blocks[i], k.ro_st[i], dseq, dseq, nq, S, nullptr, nullptr, 0, nullptr);
+        block_bwd(ro.blocks[i], k.ro_st[i], dseq, dseq, nq, S, nullptr, nullptr, 0, nullptr, Rag(), (i == 0 && k.ro_share) ? &k.ro_sh : nullptr);
       k_assemble_readout_bwd<T>(c, dseq, k.qframe, k.Bc, k.Q, L, Cl, dd, dqtok, dlatd32);
       lin_bwd_w(qenc, k.sin2, dqtok, nq);
       c->ar.release(mk);
@@ -799,6 +862,7 @@ int spa3d_create(const spa3d_config* cfg, spa3d_handle* out) {
   e = getenv("SPA3D_ATTN_IMPL"); if (e) c->attn_impl = atoi(e);
   e = getenv("SPA3D_ATTN_BWD_MODE"); if (e) c->attn_bwd_mode = atoi(e);
   e = getenv("SPA3D_PRUNE"); if (e) c->prune = atoi(e);
+  e = getenv("SPA3D_RO_SHARE"); if (e) c->ro_share = atoi(e);
   e = getenv("SPA3D_NT_OCC"); if (e) c->nt_occ = atoi(e);
   e = getenv("SPA3D_NT_8P"); if (e) c->nt_8p = atoi(e);
   e = getenv("SPA3D_NT_8PP"); if (e) c->nt_8pp = atoi(e);

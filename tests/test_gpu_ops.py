@@ -360,7 +360,7 @@ def test_attention_fused_fwd_bwd(lib, monkeypatch, nseq, S, H, masked, bwd_mode)
 
 @pytest.mark.parametrize('dtype', [BF16, F16])
 @pytest.mark.parametrize('nseq,Sq,Sk,H,masked', [(3, 128, 2048, 8, False), (2, 128, 300, 8, True), (2, 100, 129, 8, True), (5, 16, 128, 2, False),
-                                                 (1, 128, 8192, 8, False), (2, 37, 1000, 4, True)])
+                                                 (1, 128, 8192, 8, False), (2, 37, 1000, 4, True), (3, 128, 8, 8, False), (2, 128, 13, 8, True), (2, 128, 100, 8, False)])
 def test_attention_fused_cross(lib, dtype, nseq, Sq, Sk, H, masked):
   """Fused cross attention (impl=2, Sq != Sk: the 128 latents against the N track tokens, track_autoencoder_3d.py:95-100,201) vs the fp64
   oracle: keys in chunks of 128 with a split-softmax merge, dq^ partials per chunk summed before the RMSNorm backward.  Sk = 300 / 129 /

@@ -235,3 +235,53 @@ def test_token_pruning_edge_cases(monkeypatch):
     assert e < 5e-3 and abs(l - float(ld_ref['total_loss'])) < 1e-3 * abs(float(ld_ref['total_loss']))
     assert worst[0] < 0.08 and all(bool(torch.isfinite(v).all()) for v in g.values())
   assert rel_err(runs['1'][2], runs['0'][2]) < 3e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision', ['fp16', 'bf16'])
+def test_readout_shared_rows_equal_the_dense_block(monkeypatch, precision):
+  """Readout block 1 with LayerNorm / QKV once per distinct (sample, query frame) (SPA3D_RO_SHARE, default on) against the per-query
+  computation, and both against the fp64 oracle.  48 queries over 24 frames (several queries per frame, one sample with a single
+  frame for all its queries, frames 0 and T-1 present): the shared path is taken (slots <= 45 % of the queries)."""
+  import spa3d
+  cfg = O.Config(num_output_frames=24, use_dino=True, use_depth=True, dino_feature_dim=768, depth_feature_dim=1)
+  B, N, Q, T = 3, 8, 48, 24
+  batch = O.synthetic_batch(B, N, Q, T, seed=777, dino_dim=768, depth_dim=1)
+  qp = batch['query_points'].clone()
+  qp[1, :, 0] = 5.0                      # every query of sample 1 at frame 5: one slot
+  qp[2, 0, 0] = 0.0; qp[2, 1, 0] = 23.0  # first and last frame
+  batch['query_points'] = qp
+  dt16 = torch.float16 if precision == 'fp16' else torch.bfloat16
+  for k in ('dino_features', 'depth_features'):
+    batch[k] = batch[k].to(dt16).float()
+  p = O.init_params(cfg, seed=10, dtype=torch.float32, depth_dim=1, perturb=0.1)
+  noise = torch.rand(B, cfg.num_latent_tokens, cfg.latent_token_dim, generator=torch.Generator().manual_seed(3))
+  p64 = O.tree_map(lambda t: t.double(), p)
+  b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+  ld_ref, preds_ref, grads_ref = O.loss_and_grads(O.TrackAutoEncoder3D(cfg), p64, b64, discretize=True, noise=noise.double())
+  runs = {}
+  for share in ('1', '0'):
+    monkeypatch.setenv('SPA3D_RO_SHARE', share[0])
+    model = product_model(spa3d, cfg, precision)
+    gb = batch_to(batch, 'cuda')
+    for k in ('dino_features', 'depth_features'):
+      gb[k] = gb[k].to(dt16)
+    gp = O.tree_map(lambda t: t.cuda(), p)
+    ld, grads, preds = model.loss_and_grads({'params': gp}, gb, noise=noise.cuda(), return_predictions=True)
+    torch.cuda.synchronize()
+    runs[share] = (float(ld['total_loss']), O.tree_flatten(grads), preds.tracks.clone())
+  tol_t, tol_g = (5e-3, 0.08) if precision == 'fp16' else (3e-2, 0.15)
+  for share, (l, g, t) in runs.items():
+    e = rel_err(t, preds_ref.tracks)
+    worst = max((rel_err(g[k], grads_ref[k]), k) for k in grads_ref if float(grads_ref[k].norm()) > 1e-9)
+    print(f'{precision} share={share}: tracks rel vs oracle {e:.3e}, loss {l} vs {float(ld_ref["total_loss"])}, worst gradient leaf {worst}')
+  for share, (l, g, t) in runs.items():
+    e = rel_err(t, preds_ref.tracks)
+    worst = max((rel_err(g[k], grads_ref[k]), k) for k in grads_ref if float(grads_ref[k].norm()) > 1e-9)
+    assert e < tol_t and abs(l - float(ld_ref['total_loss'])) < 3e-3 * abs(float(ld_ref['total_loss']))
+    assert worst[0] < tol_g and all(bool(torch.isfinite(v).all()) for v in g.values())
+  d_t = rel_err(runs['1'][2], runs['0'][2])
+  d_g = max(rel_err(runs['1'][1][k], runs['0'][1][k]) for k in grads_ref if float(grads_ref[k].norm()) > 1e-9)
+  print(f'{precision} shared vs dense: tracks {d_t:.3e}, worst gradient leaf {d_g:.3e}')
+  assert d_t < (1e-3 if precision == 'fp16' else 8e-3)
+  assert d_g < (2e-2 if precision == 'fp16' else 0.1)
