@@ -41,7 +41,7 @@ CONFIGS = {
 # profile class -> (bound, kernel-name prefixes in the rocprofv3 summaries under profiles/)
 CLASS_INFO = {
     'gemm_nt_bf16': ('mfma', ('gemm_nt',)), 'gemm_tn_bf16': ('mfma', ('gemm_tn',)), 'gemm_generic': ('mfma', ('gemm_generic',)),
-    'attention_fused_fwd': ('hbm', ('attn_fwd',)), 'attention_fused_bwd': ('hbm', ('attn_bwd',)),
+    'attention_fused_fwd': ('hbm', ('attn_fwd', 'xattn_fwd', 'xattn_combine')), 'attention_fused_bwd': ('hbm', ('attn_bwd', 'xattn_dq_finish')),
     'layernorm_fwd': ('hbm', ('ln_fwd',)), 'layernorm_bwd': ('hbm', ('ln_bwd',)), 'attention_single_query': ('hbm', ('attn_q1',)),
 }
 
@@ -91,18 +91,21 @@ def pmc_tables():
 
 
 def pmc_traffic(rows, prefixes):
-  """HBM traffic per launch of a kernel class: (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB / dispatches -- FETCH_SIZE doubled as
-  MI355X_MICROARCH.md "HBM" prescribes for wide coalesced reads on gfx950 (an upper bound for narrower access shapes)."""
+  """HBM traffic PER STEP of a kernel class: sum over the class's kernels of (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB, divided by the
+  number of steps the PMC pass ran (= its AdamW dispatches) -- FETCH_SIZE doubled as MI355X_MICROARCH.md "HBM" prescribes for wide
+  coalesced reads on gfx950 (an upper bound for narrower access shapes)."""
   fetch = write = 0.0
-  n = 0
+  psteps = 0
   for r in rows:
+    if r['kernel'].startswith('adamw_kernel') and r['counter'] == 'FETCH_SIZE':
+      psteps = int(r['dispatches'])
     if not any(r['kernel'].startswith(p) for p in prefixes):
       continue
     if r['counter'] == 'FETCH_SIZE':
-      fetch += float(r['total']); n += int(r['dispatches'])
+      fetch += float(r['total'])
     elif r['counter'] == 'WRITE_SIZE':
       write += float(r['total'])
-  return (2.0 * fetch + write) * 1024.0 / n if n else None
+  return (2.0 * fetch + write) * 1024.0 / psteps if psteps and fetch + write > 0 else None
 
 
 def roofline_from_profile(spa3d, model, handle, steps, peak_flops, pmc=True):
@@ -120,7 +123,8 @@ def roofline_from_profile(spa3d, model, handle, steps, peak_flops, pmc=True):
       continue
     sec = c['ms'] * 1e-3
     alg = c['bytes'] / c['launches']
-    traffic = pmc_traffic(rows, prefixes) if prefixes else None
+    step_traffic = pmc_traffic(rows, prefixes) if prefixes else None                      # bytes per step, whole class
+    traffic = step_traffic * max(1, steps) / c['launches'] if step_traffic else None     # per launch, like `achieved`
     e = {'kernel': c['kernel'], 'bound': bound, 'launches': c['launches'], 'ms_per_step': round(c['ms'] / max(1, steps), 3),
          'avg_launch_ms': round(c['ms'] / c['launches'], 4)}
     if bound == 'mfma':
