@@ -555,12 +555,22 @@ template <int KT, bool X = false>
 __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, const float* kbias, const float* scq,
                                                const mfma16x8 (&qb)[3], const mfma16x8 (&dob)[3], float mq, float lq, float dq_,
                                                const u16x4 (&xraw)[6], bool valid, char* wt, bf16_t* gtile, int64_t ld_, int nrows,
-                                               float (&ds_acc)[6][4], float* dqp = nullptr) {
+                                               float (&ds_acc)[6][4], float* dqp = nullptr
+#ifdef SPA3D_ABLATE
+                                               , int ablate = 0
+#endif
+                                               ) {
   const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
   const float alpha = 0.10206207261596575f;  // 1/sqrt(96)
   mfma16x8 dsb[KT / 2];
 #pragma unroll
   for (int s2 = 0; s2 < KT / 2; ++s2) {
+#ifdef SPA3D_ABLATE
+    if (ablate & 8) {  // what a dS tile handed over through LDS would cost this role: one 16-byte read per key-tile pair, no S / dP work
+      dsb[s2] = *(const mfma16x8*)(Vs + (s2 * 32 + fr) * ROWB + fq * 16);
+      continue;
+    }
+#endif
     u16x8 t;
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
@@ -876,7 +886,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
 #endif
         bwd_query_tile<KT, X>(Ks, Vs, kbias, sscale, qb, dob, mrow[q0 + fr], lrow[q0 + fr], drow[q0 + fr], xraw, valid, wt,
                               g.dq + (row0 + q0) * g.ldq + h * DH, g.ldq, nrows_st, ds_acc,
-                              X ? g.dqpart + ((pi * g.S) + q0) * DH : nullptr);
+                              X ? g.dqpart + ((pi * g.S) + q0) * DH : nullptr
+#ifdef SPA3D_ABLATE
+                              , g.ablate
+#endif
+                              );
       }
     } else {          // ------------------------------------------------------------------ (b) key tiles -> dk, dv
       for (int kt = w; kt < QTk; kt += 4) {  // real key tiles only

@@ -37,6 +37,7 @@ def timeit(fn, n=5):
   e1.record(); torch.cuda.synchronize()
   return e0.elapsed_time(e1) / n
 assert fwd() == 0
-for mask, what in ((0, 'full'), (1, 'staging only (no tile work)'), (2, 'tile work only (no staging)'), (4, 'no dq/dk/dv stores'), (6, 'tile work, no staging, no stores')):
+for mask, what in ((0, 'full'), (1, 'staging only (no tile work)'), (2, 'tile work only (no staging)'), (4, 'no dq/dk/dv stores'), (6, 'tile work, no staging, no stores'),
+                   (8, 'dQ role without its own S / dP (dS read from LDS): upper bound of a shared-dS structure'), (14, 'the same, tile work only')):
   os.environ['SPA3D_ABLATE'] = str(mask)
   print(f'S={S} nseq={nseq} ablate={mask} [{what}]: bwd {timeit(bwd):.3f} ms', flush=True)
