@@ -56,7 +56,13 @@ __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
-constexpr int DH = 96, ROWB = DH * 2;  // 192-byte LDS rows
+constexpr int DH = 96, ROWB = DH * 2;  // 192-byte rows
+// LDS images carry 16 bytes of padding after every 4 rows: row r starts at r*192 + (r/4)*16.  With plain 192-byte rows the rows r and r+4
+// of a 16-row MFMA fragment start on the same banks (4*192 = 3*256), so every row-major ds_read_b128 fragment read -- half of the
+// kernels' LDS traffic -- was a 2-way bank conflict; per-row padding (208 B) does not fit four images of S = 151 in 160 KiB, this does.
+constexpr int ROW16 = 16 * ROWB + 64;  // bytes per 16-row block
+constexpr int img_bytes(int rows) { return rows * ROWB + (rows / 4) * 16; }  // rows % 4 == 0
+__device__ __forceinline__ int row_off(int r) { return r * ROWB + (r >> 2) * 16; }
 constexpr bool fwd_wide(int KT, int NW) { return KT <= 10 || NW == 8; }
 
 // Block -> problem map.  The dispatcher deals blocks round-robin over the 8 XCDs (observed, speed only), so blocks b, b+8, ..
@@ -111,7 +117,7 @@ __device__ __forceinline__ void rows_store(RawRows<NP>& r, int S_pad, const floa
         for (int j = 0; j < 8; ++j) r.x[ps][c][j] = f2bf(f[c * 8 + j] * rr * scale[(part + 4 * c) * 8 + j]);
     }
     if (row < S_pad) {
-      u16x8* d = (u16x8*)(lds + row * ROWB) + part;
+      u16x8* d = (u16x8*)(lds + row_off(row)) + part;
       d[0] = r.x[ps][0]; d[4] = r.x[ps][1]; d[8] = r.x[ps][2];
     }
   }
@@ -161,7 +167,7 @@ template <int KT, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs g) {
   constexpr int S_pad = KT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem; char* Vs = smem + S_pad * ROWB; float* kbias = (float*)(smem + 2 * S_pad * ROWB);
+  char* Ks = smem; char* Vs = smem + img_bytes(S_pad); float* kbias = (float*)(smem + 2 * img_bytes(S_pad));
   constexpr bool WIDE = fwd_wide(KT, NW);  // output rows through a wave tile (not where it would cost the second workgroup per CU)
   char* wt = (char*)(kbias + S_pad) + (threadIdx.x >> 6) * WTILE;
   const int64_t prob = map_prob(blockIdx.x, g.nprob / g.H, g.H);
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs g) {
         acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-          const mfma16x8 kf = *(const mfma16x8*)(Ks + (kt * 16 + fr) * ROWB + (s * 32 + fq * 8) * 2);
+          const mfma16x8 kf = *(const mfma16x8*)(Ks + kt * ROW16 + row_off(fr) + (s * 32 + fq * 8) * 2);
           acc[kt] = MFMA16(kf, qb[s], acc[kt]);
         }
       }
@@ -243,14 +249,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs g) {
       }
       // ---- O^T[d][q] = sum_keys V^T[d][key] P^T[key][q]
       const int tq = fr >> 2, tp = fr & 3;  // this lane's slot in its 16-lane transposed-read group
-      const char* vbase = Vs + tp * 8 + (4 * fq + tq) * ROWB;
+      const char* vbase = Vs + tp * 8 + row_off(4 * fq + tq);
       static_for<0, 6>([&](auto dtc) {
         constexpr int dt = decltype(dtc)::value;
         f32x4 oacc = f32x4{0.f, 0.f, 0.f, 0.f};
         uint2 lo[KT / 2], hi[KT / 2];
         static_for<0, KT / 2>([&](auto sc_) {
           constexpr int s2 = decltype(sc_)::value;
-          lo[s2] = lds_tr16_b64_o<dt * 32 + 32 * s2 * ROWB>(vbase); hi[s2] = lds_tr16_b64_o<dt * 32 + (32 * s2 + 16) * ROWB>(vbase);
+          lo[s2] = lds_tr16_b64_o<dt * 32 + 2 * s2 * ROW16>(vbase); hi[s2] = lds_tr16_b64_o<dt * 32 + (2 * s2 + 1) * ROW16>(vbase);
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);  // MFMAs must stay below the wait (cdna_hip_programming.md rule 18)
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs g) {
 
 template <int KT, int NW>
 static void launch_fwd(spa3d_ctx* c, const AttnArgs& a) {
-  const int lds = 2 * KT * 16 * ROWB + KT * 16 * 4 + (fwd_wide(KT, NW) ? NW * WTILE : 0);
+  const int lds = 2 * img_bytes(KT * 16) + KT * 16 * 4 + (fwd_wide(KT, NW) ? NW * WTILE : 0);
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<KT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
   attn_fwd_kernel<KT, NW><<<(unsigned)a.nprob, NW * 64, lds, c->stream>>>(a);
@@ -298,7 +304,7 @@ struct XAttnArgs {
 __global__ __launch_bounds__(256, 2) void xattn_fwd_kernel(XAttnArgs g) {
   constexpr int KT = XCHUNK / 16, NW = 4, S_pad = XCHUNK, RPP = NW * 16, NP = S_pad / RPP, NT = KT / NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem; char* Vs = smem + S_pad * ROWB; float* kbias = (float*)(smem + 2 * S_pad * ROWB);
+  char* Ks = smem; char* Vs = smem + img_bytes(S_pad); float* kbias = (float*)(smem + 2 * img_bytes(S_pad));
   const int64_t pi = blockIdx.x, prob = pi / g.nsplit; const int sp = (int)(pi - prob * g.nsplit);
   const int64_t seq = prob / g.H; const int h = (int)(prob - seq * g.H);
   const int64_t qrow0 = seq * g.Sq, krow0 = seq * g.Sk + (int64_t)sp * S_pad;
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fwd_kernel(XAttnArgs g) {
         acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-          const mfma16x8 kf = *(const mfma16x8*)(Ks + (kt * 16 + fr) * ROWB + (s * 32 + fq * 8) * 2);
+          const mfma16x8 kf = *(const mfma16x8*)(Ks + kt * ROW16 + row_off(fr) + (s * 32 + fq * 8) * 2);
           acc[kt] = MFMA16(kf, qb[s], acc[kt]);
         }
       }
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fwd_kernel(XAttnArgs g) {
         pb[s2] = __builtin_bit_cast(mfma16x8, t);
       }
       const int tq = fr >> 2, tp = fr & 3;
-      const char* vbase = Vs + tp * 8 + (4 * fq + tq) * ROWB;
+      const char* vbase = Vs + tp * 8 + row_off(4 * fq + tq);
       float* op = g.opart + (pi * Sq + q0 + fr) * DH + fq * 4;
       static_for<0, 6>([&](auto dtc) {
         constexpr int dt = decltype(dtc)::value;
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void xattn_fwd_kernel(XAttnArgs g) {
         uint2 lo[KT / 2], hi[KT / 2];
         static_for<0, KT / 2>([&](auto sc_) {
           constexpr int s2 = decltype(sc_)::value;
-          lo[s2] = lds_tr16_b64_o<dt * 32 + 32 * s2 * ROWB>(vbase); hi[s2] = lds_tr16_b64_o<dt * 32 + (32 * s2 + 16) * ROWB>(vbase);
+          lo[s2] = lds_tr16_b64_o<dt * 32 + 2 * s2 * ROW16>(vbase); hi[s2] = lds_tr16_b64_o<dt * 32 + (2 * s2 + 1) * ROW16>(vbase);
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -468,7 +474,7 @@ static bool xattn_fwd(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const bf16
   if (!c->dry) {
     ProfScope ps(c, PROF_ATTN_FWD, 4.0 * (double)nprob * Sq * Sk * DH, (double)nprob * (2.0 * Sq + 2.0 * Sk) * DH * 2.0);
     ps.tag(nseq, Sk, H, Sq);
-    const int lds = 2 * XCHUNK * ROWB + XCHUNK * 4;
+    const int lds = 2 * img_bytes(XCHUNK) + XCHUNK * 4;
     xattn_fwd_kernel<<<(unsigned)(nprob * nsplit), 256, lds, c->stream>>>(a);
     const int64_t nrows = nprob * Sq;
     xattn_combine_kernel<<<(unsigned)((nrows + 3) / 4), 256, 0, c->stream>>>(a.opart, a.mlpart, nsplit, Sq, H, nrows, o, lse);
@@ -525,7 +531,7 @@ bool attn_fused_fwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const b
 // P is rebuilt from the forward's (row max, log row sum); delta = rowsum(dO o O).
 //
 // Two workgroup structures over the same two tile routines:
-//   attn_bwd8_kernel     (S <= 192)  all four images resident (4 x 30 KiB at S = 151); waves 0-3 run (a) while waves 4-7 run (b)
+//   attn_bwd8_kernel     (S <= 160)  all four images resident (4 x 31 KiB at S = 151); waves 0-3 run (a) while waves 4-7 run (b)
 //                                    on the shared images: two waves per SIMD, compute = max(a, b); one workgroup per CU.
 //   attn_bwd_split_kernel (S <= 320) two passes per problem over TWO images: pass A stages K^, V and every wave takes query
 //                                    tiles (its own q^/dO fragments come straight from global memory), pass B re-uses the
@@ -567,7 +573,7 @@ __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, c
   for (int s2 = 0; s2 < KT / 2; ++s2) {
 #ifdef SPA3D_ABLATE
     if (ablate & 8) {  // what a dS tile handed over through LDS would cost this role: one 16-byte read per key-tile pair, no S / dP work
-      dsb[s2] = *(const mfma16x8*)(Vs + (s2 * 32 + fr) * ROWB + fq * 16);
+      dsb[s2] = *(const mfma16x8*)(Vs + 2 * s2 * ROW16 + row_off(fr) + fq * 16);
       continue;
     }
 #endif
@@ -578,8 +584,8 @@ __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, c
       f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
-        const mfma16x8 kf = *(const mfma16x8*)(Ks + (kt * 16 + fr) * ROWB + (s * 32 + fq * 8) * 2);
-        const mfma16x8 vf = *(const mfma16x8*)(Vs + (kt * 16 + fr) * ROWB + (s * 32 + fq * 8) * 2);
+        const mfma16x8 kf = *(const mfma16x8*)(Ks + kt * ROW16 + row_off(fr) + (s * 32 + fq * 8) * 2);
+        const mfma16x8 vf = *(const mfma16x8*)(Vs + kt * ROW16 + row_off(fr) + (s * 32 + fq * 8) * 2);
         st = MFMA16(kf, qb[s], st);
         dpt = MFMA16(vf, dob[s], dpt);
       }
@@ -596,14 +602,14 @@ __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, c
   }
   // dQ^^T[d][q] = sum_keys K^^T[d][key] dS^T[key][q]  (already times alpha)
   f32x4 dqa[6];
-  const char* kbase = Ks + tp * 8 + (4 * fq + tq) * ROWB;
+  const char* kbase = Ks + tp * 8 + row_off(4 * fq + tq);
   static_for<0, 6>([&](auto dtc) {
     constexpr int dt = decltype(dtc)::value;
     dqa[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     uint2 lo[KT / 2], hi[KT / 2];
     static_for<0, KT / 2>([&](auto sc_) {
       constexpr int s2 = decltype(sc_)::value;
-      lo[s2] = lds_tr16_b64_o<dt * 32 + 32 * s2 * ROWB>(kbase); hi[s2] = lds_tr16_b64_o<dt * 32 + (32 * s2 + 16) * ROWB>(kbase);
+      lo[s2] = lds_tr16_b64_o<dt * 32 + 2 * s2 * ROW16>(kbase); hi[s2] = lds_tr16_b64_o<dt * 32 + (2 * s2 + 1) * ROW16>(kbase);
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -675,8 +681,8 @@ __device__ __forceinline__ void bwd_key_tile(const char* Qs, const char* dOs, co
       f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
-        const mfma16x8 qf = *(const mfma16x8*)(Qs + (qt * 16 + fr) * ROWB + (s * 32 + fq * 8) * 2);
-        const mfma16x8 df = *(const mfma16x8*)(dOs + (qt * 16 + fr) * ROWB + (s * 32 + fq * 8) * 2);
+        const mfma16x8 qf = *(const mfma16x8*)(Qs + qt * ROW16 + row_off(fr) + (s * 32 + fq * 8) * 2);
+        const mfma16x8 df = *(const mfma16x8*)(dOs + qt * ROW16 + row_off(fr) + (s * 32 + fq * 8) * 2);
         st = MFMA16(qf, kb[s], st);     // S[q = 16qt+4fq+r][key = k0+fr]
         dpt = MFMA16(df, vb[s], dpt);   // dP[q][key]
       }
@@ -693,12 +699,12 @@ __device__ __forceinline__ void bwd_key_tile(const char* Qs, const char* dOs, co
     const mfma16x8 pb = __builtin_bit_cast(mfma16x8, tp_), dsb = __builtin_bit_cast(mfma16x8, tds);
     // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^^T[d][key] += Q^^T[d][q] dS[q][key]
     uint2 olo[6], ohi[6], qlo[6], qhi[6];
-    const int roff = (32 * s2 + 4 * fq + tq) * ROWB + tp * 8;
+    const int roff = 2 * s2 * ROW16 + row_off(4 * fq + tq) + tp * 8;
     const char* ob = dOs + roff; const char* qb_ = Qs + roff;
     static_for<0, 6>([&](auto dtc) {
       constexpr int dt = decltype(dtc)::value;
-      olo[dt] = lds_tr16_b64_o<dt * 32>(ob); ohi[dt] = lds_tr16_b64_o<16 * ROWB + dt * 32>(ob);
-      qlo[dt] = lds_tr16_b64_o<dt * 32>(qb_); qhi[dt] = lds_tr16_b64_o<16 * ROWB + dt * 32>(qb_);
+      olo[dt] = lds_tr16_b64_o<dt * 32>(ob); ohi[dt] = lds_tr16_b64_o<ROW16 + dt * 32>(ob);
+      qlo[dt] = lds_tr16_b64_o<dt * 32>(qb_); qhi[dt] = lds_tr16_b64_o<ROW16 + dt * 32>(qb_);
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -765,7 +771,7 @@ __device__ __forceinline__ void store_do_delta(const RawRows<NP>& xd, const RawR
       for (int j = 0; j < 8; ++j) dsum += bf2f(xd.x[ps][c][j]) * bf2f(xo.x[ps][c][j]);
     dsum += __shfl_xor(dsum, 1, 64); dsum += __shfl_xor(dsum, 2, 64);
     if (row < S_pad) {
-      u16x8* d = (u16x8*)(dOs + row * ROWB) + part;
+      u16x8* d = (u16x8*)(dOs + row_off(row)) + part;
       d[0] = xd.x[ps][0]; d[4] = xd.x[ps][1]; d[8] = xd.x[ps][2];
       if (part == 0) drow[row] = dsum;
     }
@@ -805,8 +811,8 @@ template <int KT, bool X = false>
 __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
   constexpr int S_pad = KT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Qs = smem; char* Ks = Qs + S_pad * ROWB; char* Vs = Ks + S_pad * ROWB; char* dOs = Vs + S_pad * ROWB;
-  float* kbias = (float*)(dOs + S_pad * ROWB); float* mrow = kbias + S_pad; float* lrow = mrow + S_pad; float* drow = lrow + S_pad;
+  char* Qs = smem; char* Ks = Qs + img_bytes(S_pad); char* Vs = Ks + img_bytes(S_pad); char* dOs = Vs + img_bytes(S_pad);
+  float* kbias = (float*)(dOs + img_bytes(S_pad)); float* mrow = kbias + S_pad; float* lrow = mrow + S_pad; float* drow = lrow + S_pad;
   float* sred = drow + S_pad;     // [2][96] scale-gradient staging
   float* sscale = sred + 2 * DH;  // [2][96] RMSNorm scales (LDS copies: as loop invariants in registers they cost 48 VGPRs)
   char* wt = (char*)(sscale + 2 * DH) + (threadIdx.x >> 6) * WTILE;  // wave-private output tile
@@ -876,8 +882,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
         mfma16x8 qb[3], dob[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-          qb[s] = *(const mfma16x8*)(Qs + (q0 + fr) * ROWB + (s * 32 + fq * 8) * 2);
-          dob[s] = *(const mfma16x8*)(dOs + (q0 + fr) * ROWB + (s * 32 + fq * 8) * 2);
+          qb[s] = *(const mfma16x8*)(Qs + qt * ROW16 + row_off(fr) + (s * 32 + fq * 8) * 2);
+          dob[s] = *(const mfma16x8*)(dOs + qt * ROW16 + row_off(fr) + (s * 32 + fq * 8) * 2);
         }
 #ifdef SPA3D_ABLATE
         const int nrows_st = (g.ablate & 4) ? 0 : S - q0;
@@ -905,8 +911,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
         mfma16x8 kb[3], vb[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-          kb[s] = *(const mfma16x8*)(Ks + (k0 + fr) * ROWB + (s * 32 + fq * 8) * 2);
-          vb[s] = *(const mfma16x8*)(Vs + (k0 + fr) * ROWB + (s * 32 + fq * 8) * 2);
+          kb[s] = *(const mfma16x8*)(Ks + kt * ROW16 + row_off(fr) + (s * 32 + fq * 8) * 2);
+          vb[s] = *(const mfma16x8*)(Vs + kt * ROW16 + row_off(fr) + (s * 32 + fq * 8) * 2);
         }
 #ifdef SPA3D_ABLATE
         const int nrows_st = (g.ablate & 4) ? 0 : Sk - k0;
@@ -921,13 +927,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
   flush_scale_grads<512>(g, sred, ds_acc, ds_acc, !X && role == 0, role == 1);
 }
 
-// split-pass form, two images: see the section header.  NW waves per workgroup (4: two workgroups per CU at S <= 192; 8: one).
+// split-pass form, two images: see the section header.  NW waves per workgroup (4: two workgroups per CU at S <= 160; 8: one).
 template <int KT, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_split_kernel(AttnBwdArgs g) {
   constexpr int S_pad = KT * 16, NTH = NW * 64, RPP = NW * 16, NP = (S_pad + RPP - 1) / RPP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* B0 = smem; char* B1 = B0 + S_pad * ROWB;  // pass A: K^, V ; pass B: Q^, dO
-  float* kbias = (float*)(B1 + S_pad * ROWB); float* mrow = kbias + S_pad; float* lrow = mrow + S_pad; float* drow = lrow + S_pad;
+  char* B0 = smem; char* B1 = B0 + img_bytes(S_pad);  // pass A: K^, V ; pass B: Q^, dO
+  float* kbias = (float*)(B1 + img_bytes(S_pad)); float* mrow = kbias + S_pad; float* lrow = mrow + S_pad; float* drow = lrow + S_pad;
   float* sred = drow + S_pad; float* sscale = sred + 2 * DH;
   char* wtile = (char*)(sscale + 2 * DH);  // wave-private tiles: own-row staging in pass A, output rows in both passes
   const int E = g.H * DH;
@@ -997,11 +1003,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_split_kernel(AttnBwdArgs 
         for (int c = 0; c < 3; ++c)
 #pragma unroll
           for (int j = 0; j < 8; ++j) xq[c][j] = f2bf(f[c * 8 + j] * rr * sscale[(part + 4 * c) * 8 + j]);
-        u16x8* d = (u16x8*)(wt + tr * ROWB) + part;
+        u16x8* d = (u16x8*)(wt + tr * WROW) + part;
         d[0] = xq[0]; d[4] = xq[1]; d[8] = xq[2];
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int s = 0; s < 3; ++s) qb[s] = *(const mfma16x8*)(wt + fr * ROWB + (s * 32 + fq * 8) * 2);
+        for (int s = 0; s < 3; ++s) qb[s] = *(const mfma16x8*)(wt + fr * WROW + (s * 32 + fq * 8) * 2);
         asm volatile("" ::: "memory");
       }
       float dsum = 0.f;
@@ -1011,12 +1017,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_split_kernel(AttnBwdArgs 
 #pragma unroll
           for (int j = 0; j < 8; ++j) dsum += bf2f(xd[c][j]) * bf2f(xo[c][j]);
         dsum += __shfl_xor(dsum, 1, 64); dsum += __shfl_xor(dsum, 2, 64);
-        u16x8* d = (u16x8*)(wt + tr * ROWB) + part;
+        u16x8* d = (u16x8*)(wt + tr * WROW) + part;
         d[0] = xd[0]; d[4] = xd[1]; d[8] = xd[2];
         if (part == 0) wdel[tr] = dsum;
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int s = 0; s < 3; ++s) dob[s] = *(const mfma16x8*)(wt + fr * ROWB + (s * 32 + fq * 8) * 2);
+        for (int s = 0; s < 3; ++s) dob[s] = *(const mfma16x8*)(wt + fr * WROW + (s * 32 + fq * 8) * 2);
         dsum = wdel[fr];
         asm volatile("" ::: "memory");
       }
@@ -1065,22 +1071,22 @@ template <int KT>
 static void launch_bwd(spa3d_ctx* c, const AttnBwdArgs& a) {
   constexpr int S_pad = KT * 16;
   const int small = 4 * S_pad * 4 + 4 * DH * 4;
-  const int lds4 = 4 * S_pad * ROWB + small + 8 * WTILE;
-  auto lds2 = [&](int nw) { return 2 * S_pad * ROWB + small + nw * WTILE; };
-  // mode 1: four resident images, concurrent roles (S <= 192); 2: split-pass, 4 waves, two workgroups per CU; 3: split-pass, 8 waves
+  const int lds4 = 4 * img_bytes(S_pad) + small + 8 * WTILE;
+  auto lds2 = [&](int nw) { return 2 * img_bytes(S_pad) + small + nw * WTILE; };
+  // mode 1: four resident images, concurrent roles (S <= 160); 2: split-pass, 4 waves, two workgroups per CU; 3: split-pass, 8 waves
   int mode = c->attn_bwd_mode;
-  if (S_pad > 192) mode = 3;
+  if (S_pad > 160) mode = 3;  // four images + wave tiles fit 160 KiB up to S = 160
   else if (mode == 0) mode = 1;
   static bool attr_set = false;
   if (!attr_set) {
-    if constexpr (S_pad <= 192) {
+    if constexpr (S_pad <= 160) {
       (void)hipFuncSetAttribute((const void*)attn_bwd8_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
       (void)hipFuncSetAttribute((const void*)attn_bwd_split_kernel<KT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2(4));
     }
     (void)hipFuncSetAttribute((const void*)attn_bwd_split_kernel<KT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2(8));
     attr_set = true;
   }
-  if constexpr (S_pad <= 192) {
+  if constexpr (S_pad <= 160) {
     if (mode == 1) { attn_bwd8_kernel<KT><<<(unsigned)std::min<int64_t>(a.nprob, 1024), 512, lds4, c->stream>>>(a); return; }
     if (mode == 2) { attn_bwd_split_kernel<KT, 4><<<(unsigned)std::min<int64_t>(a.nprob, 2048), 256, lds2(4), c->stream>>>(a); return; }
   }
@@ -1110,7 +1116,7 @@ bool attn_fused_bwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const b
       ProfScope ps(c, PROF_ATTN_BWD, 14.0 * (double)nprob * Sq * Sk * DH, (double)nprob * (4.0 * Sq + 4.0 * Sk) * DH * 2.0);
       ps.tag(nseq, Sk, H, Sq);
       constexpr int KT = XCHUNK / 16;
-      const int lds4 = 4 * XCHUNK * ROWB + 4 * XCHUNK * 4 + 4 * DH * 4 + 8 * WTILE;
+      const int lds4 = 4 * img_bytes(XCHUNK) + 4 * XCHUNK * 4 + 4 * DH * 4 + 8 * WTILE;
       static bool attr_set = false;
       if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd8_kernel<KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4); attr_set = true; }
       attn_bwd8_kernel<KT, true><<<(unsigned)std::min<int64_t>(nprob * nsplit, 1024), 512, lds4, c->stream>>>(a);
