@@ -57,12 +57,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 constexpr int DH = 96, ROWB = DH * 2;  // 192-byte rows
-// LDS images carry 16 bytes of padding after every 4 rows: row r starts at r*192 + (r/4)*16.  With plain 192-byte rows the rows r and r+4
-// of a 16-row MFMA fragment start on the same banks (4*192 = 3*256), so every row-major ds_read_b128 fragment read -- half of the
-// kernels' LDS traffic -- was a 2-way bank conflict; per-row padding (208 B) does not fit four images of S = 151 in 160 KiB, this does.
-constexpr int ROW16 = 16 * ROWB + 64;  // bytes per 16-row block
-constexpr int img_bytes(int rows) { return rows * ROWB + (rows / 4) * 16; }  // rows % 4 == 0
-__device__ __forceinline__ int row_off(int r) { return r * ROWB + (r >> 2) * 16; }
+// LDS images carry 32 bytes of padding after every 4 rows: row r starts at r*192 + (r/4)*32.  With plain 192-byte rows both kinds of
+// fragment read were 2-way bank conflicts (MI355X_MICROARCH.md "LDS": ds_read_b128 is served in four fixed 16-lane groups, the
+// transposed ds_read_b64_tr_b16 in 32-lane halves; rows r and r+4 start on the same banks, 4*192 = 3*256); this is the smallest padding
+// for which the 16 lanes of every b128 group hit 16 distinct 16-byte slots AND the 32 lanes of every transposed-read half hit 32
+// distinct 8-byte slots (exhaustive search over per-row paddings).  Per-row padding (208 B) would not fit four images of S = 151.
+constexpr int ROW16 = 16 * ROWB + 128;  // bytes per 16-row block
+constexpr int img_bytes(int rows) { return rows * ROWB + (rows / 4) * 32; }  // rows % 4 == 0
+__device__ __forceinline__ int row_off(int r) { return r * ROWB + (r >> 2) * 32; }
 constexpr bool fwd_wide(int KT, int NW) { return KT <= 10 || NW == 8; }
 
 // Block -> problem map.  The dispatcher deals blocks round-robin over the 8 XCDs (observed, speed only), so blocks b, b+8, ..
