@@ -19,8 +19,11 @@
  *
  * Rules: plain C; every function returns an int status (0 = ok) and never throws; no
  * allocation inside (the caller supplies one workspace from its own allocator); every call
- * is asynchronous on the hipStream_t passed as `void* stream`; one handle per stream
- * (thread-compatible, not thread-safe).  All tensors are row-major contiguous in the
+ * is asynchronous on the hipStream_t passed as `void* stream` -- except that, in the 16-bit
+ * modes, two 4-byte plan counts per sample chunk (kept frame tokens; distinct query frames) are
+ * read back to the host, which synchronises the stream at those points (SPA3D_PRUNE=0 /
+ * SPA3D_RO_SHARE=0 in the environment remove the reads together with the savings they size);
+ * one handle per stream (thread-compatible, not thread-safe).  All tensors are row-major contiguous in the
  * reference's layouts.  Parameters and gradients are ONE flat float32 buffer each whose
  * leaf order / offsets the library defines (spa3d_leaf_*); names are the Flax paths of
  * SURVEY.md 0.3 and shapes are Flax shapes ([in,out] kernels, [in,H,Dh] / [H,Dh,out]).
