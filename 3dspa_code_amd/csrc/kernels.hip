@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(256) void share_plan_finish_kernel(const int32_t* _
 int64_t k_share_plan(spa3d_ctx* c, const int32_t* qframe, int64_t B, int Q, int32_t* slot, int32_t* slot_b, int32_t* slot_f, int32_t* slot_q0,
                      int32_t* scratch /*[B*Q + B + 1]*/) {
   if (c->dry) return B * Q;
-  if (B > 1024 || Q > 12288) { if (!c->hip_err) { c->hip_err = -6; c->err = "share plan: at most 1024 samples per chunk and 12288 queries"; } return B * Q; }
+  if (B > 1024 || Q > 12288) return B * Q;  // outside the plan kernels' LDS tables: every query its own slot, i.e. the caller keeps the dense path
   int32_t* first_q = scratch; int32_t* nslot_b = scratch + B * Q; int32_t* total = nslot_b + B;
   share_plan_kernel<<<(unsigned)B, 256, Q * sizeof(int32_t), c->stream>>>(qframe, Q, slot, nslot_b, first_q); SPA_LAUNCH_CHECK(c);
   share_plan_finish_kernel<<<1, 256, 0, c->stream>>>(qframe, (int)B, Q, slot, nslot_b, first_q, slot_b, slot_f, slot_q0, total); SPA_LAUNCH_CHECK(c);

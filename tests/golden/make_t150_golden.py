@@ -15,6 +15,7 @@ Cases (BASELINE.json configs[1] and configs[2] channel sets):
   c772 : xyz + depth(1) + DINOv2-768, B=2, N=6, Q=4, boundary_frame = (150, 97)
   c4   : xyz + depth(1) only (depth-only parametrisation, cfg#2), same sizes
   c772_t300 : T = T_out = 300, B=1, N=4, Q=8 (BASELINE configs[4] sequence length; see the case table)
+  c772_q320 : B=1, N=6, Q=320: several queries per frame (the shared-latent-row path of the readout stack's first block)
   c772_tiles : B=2, N=64, Q=64 -> M = 19 328 track-token rows and 16 512 readout rows, i.e. above the 16 384-row
          threshold at which the default dispatch takes the 8-phase / persistent MFMA kernels the benchmark runs on.
 bf16 inputs: DINO / depth features are rounded to bf16 before the oracle sees them (the product's bf16 mode stores
@@ -40,6 +41,9 @@ CASES = {
     # BASELINE configs[4] sequence length: T = T_out = 300 (S = 301).  Query frames are set by hand so that floor(t / 150) takes
     # both values (track_autoencoder_3d.py:268-269) and the 128-wide window lat[:, 5t : 5t+128] runs partly (t = 205..230) and
     # wholly (t >= 231) off the end of the 1152 latent channels (:239-245).
+    # 320 queries over 150 frames (about 130 distinct frames: below the 45 % threshold at which the product computes readout block 1's
+    # LayerNorm / QKV once per distinct (sample, query frame), DESIGN.md "Shared latent rows"): the benchmark's regime, many queries per frame
+    'c772_q320': dict(B=1, N=6, Q=320, dino=768, depth=1, boundary=(150,), pseed=5, bseed=81),
     'c772_t300': dict(B=1, N=4, Q=8, T=300, dino=768, depth=1, boundary=(260,), pseed=8, bseed=80, qframes=(0, 149, 150, 204, 205, 230, 231, 299)),
 }
 KEEP_GRADS = ('input_readout_token/state_init', 'depth_projection/kernel', 'track_token_projection/bias',

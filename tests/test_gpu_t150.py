@@ -88,7 +88,7 @@ def _leaf_report(gf, exp, tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', ['c772', 'c4', 'c772_t300'])
+@pytest.mark.parametrize('case', ['c772', 'c4', 'c772_t300', 'c772_q320'])
 def test_t150_fp32_vs_oracle_golden(case):
   import spa3d
   cfg, p, batch, noise, exp = _case(case)
@@ -106,9 +106,10 @@ def test_t150_fp32_vs_oracle_golden(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('case', ['c772', 'c4', 'c772_t300'])
+@pytest.mark.parametrize('case', ['c772', 'c4', 'c772_t300', 'c772_q320'])
 def test_t150_bf16_vs_oracle_golden(case):
-  """The benchmarked arithmetic (bf16 activations, default kernels) against the fp64 oracle directly."""
+  """The benchmarked arithmetic (bf16 activations, default kernels) against the fp64 oracle directly.  c772_q320 (320 queries over 150
+  frames) takes the shared-latent-row path of the readout stack's first block, as the benchmark does."""
   import spa3d
   cfg, p, batch, noise, exp = _case(case)
   ld, gf, preds, lat = _run(spa3d, cfg, p, batch, noise, 'bf16')
