@@ -85,10 +85,12 @@ def test_2d_forward_loss_grads_fp32(spa3d):
 
 
 @pytest.mark.gpu
-def test_2d_default_size_bf16_runs_and_tracks_fp32(spa3d):
-  """default TRAJAN sizes (d=256, heads of 64, 2/6/3/4 layers): bf16 path vs the fp32 path of the same library"""
+@pytest.mark.parametrize('Q', [16, 64])
+def test_2d_default_size_bf16_runs_and_tracks_fp32(spa3d, Q):
+  """default TRAJAN sizes (d=256, heads of 64, 2/6/3/4 layers): bf16 path vs the fp32 path of the same library.  Q = 64 over 24 frames:
+  the bf16 run takes the shared-latent-row path of the readout stack's first block (several queries per frame), the fp32 run the dense one."""
   cfg = O.config_2d(num_output_frames=24)
-  B, N, Q, T = 2, 48, 16, 24
+  B, N, T = 2, 48, 24
   batch = O.synthetic_batch_2d(B, N, Q, T)
   gb = batch_to(batch, 'cuda')
   noise = torch.rand(B, 128, 64).cuda()
