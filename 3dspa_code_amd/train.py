@@ -87,12 +87,14 @@ class TrainState:
   (tests/test_dp_gloo.py) with a stand-in compute.
     compute(params_tree, batch, grads_flat, denom, discretize, noise) -> {'total_loss','position_loss','visible_loss'}
     adamw(flat, grads, m, v, lr, step, clip, b1, b2, eps, wd, scratch) -> None  (scratch[0] := global grad norm)
-    noise_fn(n, device) -> float32[n] = jax.random.uniform(PRNGKey(0), [n]) (track_autoencoder_3d.py:254-257)"""
+    noise_fn(n, device) -> float32[n] = jax.random.uniform(PRNGKey(0), [n]) (track_autoencoder_3d.py:254-257)
+    evaluate(params_tree, batch, denom, discretize, noise) -> (loss dict, predictions)   (eval_step, train.py:189-213)"""
 
   def __init__(self, model: TrackAutoEncoder3D, params, learning_rate: float = 1e-4, warmup_steps: int = 10000,
                total_steps: int = 1000000, weight_decay: float = 0.01, clip_norm: float = 1.0, b1: float = 0.9,
                b2: float = 0.999, eps: float = 1e-8, process_group: Optional[dist.ProcessGroup] = None,
-               grad_bucket_bytes: int = 128 << 20, compute=None, adamw=None, noise_fn=None, force_collectives: bool = False):
+               grad_bucket_bytes: int = 128 << 20, compute=None, adamw=None, noise_fn=None, force_collectives: bool = False,
+               evaluate=None):
     self.model = model
     self.params = params if hasattr(params, 'flat') and params.flat is not None else None
     flat = model.flat_from_tree(params)
@@ -116,6 +118,7 @@ class TrainState:
     self._compute = compute or self._hip_compute
     self._adamw = adamw or self._hip_adamw
     self._noise_fn = noise_fn or _hip_uniform_noise
+    self._evaluate = evaluate or self._hip_evaluate
     self._noise_cache = {}
     self.sync_from_rank0()
 
@@ -132,6 +135,12 @@ class TrainState:
   def _hip_adamw(self, flat, grads, m, v, lr, step, clip, b1, b2, eps, wd, scratch):
     _lib.check(_lib.load().spa3d_adamw_step(flat.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(), flat.numel(), lr, step,
                                             clip, b1, b2, eps, wd, scratch.data_ptr(), _stream(flat)), what='spa3d_adamw_step')
+
+  def _hip_evaluate(self, params, batch, denom, discretize, noise):
+    from .model import compute_loss_2d, compute_loss_3d
+    preds = self.model.apply({'params': params}, batch, discretize=discretize, noise=noise)
+    loss_fn = compute_loss_2d if preds.tracks.shape[-1] == 2 else compute_loss_3d
+    return loss_fn(preds, batch, denom=denom), preds
 
   def rank_noise(self, b_local: int):
     """The reference draws uniform(PRNGKey(0), [B_global, L, Ld]) over the GLOBAL batch (3d:254-258); rank r owns rows
@@ -159,3 +168,19 @@ class TrainState:
     # metric keys of train.py:180-185 (device scalars)
     return {'train/loss': l3[0], 'train/position_loss': l3[1], 'train/visible_loss': l3[2], 'train/learning_rate': lr,
             'train/grad_norm': self.scratch[0]}
+
+  def eval_step(self, batch, discretize: bool = True, noise=None):
+    """train.py:189-213: forward pass + compute_loss on the current parameters, no update.  Returns (metrics, predictions) with the
+    reference's metric keys 'eval/loss', 'eval/position_loss', 'eval/visible_loss' (device scalars).  Under data parallelism the two
+    loss terms are normalised by the GLOBAL visible count and summed over ranks, exactly as the training loss is, and the rank
+    takes its slice of the global discretisation noise; predictions are the rank's own."""
+    multi = self.world > 1 or self.force
+    denom = global_visible_count(batch['query_tracks_visible'], self.pg, self.force) if multi else 0.0
+    if multi and discretize and noise is None:
+      noise = self.rank_noise(batch['query_tracks_visible'].shape[0])
+    ld, preds = self._evaluate(self.params, batch, denom, discretize, noise)
+    l3 = torch.stack([torch.as_tensor(ld[k], dtype=torch.float32, device=self.flat.device).reshape(())
+                      for k in ('total_loss', 'position_loss', 'visible_loss')])
+    if _collectives_on(self.pg, self.force):
+      dist.all_reduce(l3, op=dist.ReduceOp.SUM, group=self.pg)
+    return {'eval/loss': l3[0], 'eval/position_loss': l3[1], 'eval/visible_loss': l3[2]}, preds

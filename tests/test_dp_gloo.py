@@ -112,6 +112,12 @@ def _oracle_hooks(cfg, names_shapes):
   def noise_fn(n, device):
     return torch.from_numpy(NB.jax_uniform_legacy((n,), (0, 0)).astype(np.float32)).to(device)
 
+  def evaluate(params, batch, denom, discretize, noise):
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    preds = m(to_tree(params), b64, discretize=discretize, noise=None if noise is None else noise.double())
+    return O.compute_loss_3d(preds, b64, denom=denom if denom > 0 else None), preds
+
+  compute.evaluate = evaluate
   return compute, adamw, noise_fn
 
 
@@ -133,11 +139,12 @@ def _ts_worker(rank, world, port, q):
     _, leaves, n = model._handle(0, 0)
     compute, adamw, noise_fn = _oracle_hooks(cfg, leaves)
     st = spa3d.TrainState(model, params, learning_rate=1e-2, warmup_steps=1, total_steps=10, grad_bucket_bytes=4000, compute=compute,
-                          adamw=adamw, noise_fn=noise_fn)
+                          adamw=adamw, noise_fn=noise_fn, evaluate=compute.evaluate)
     ref0 = model.flat_from_tree(O.init_params(cfg, seed=5, dtype=torch.float32, with_dino=False, with_depth=False, perturb=0.1))
     bcast_ok = bool(torch.equal(st.flat, ref0))
     lo, hi = rank * B // world, (rank + 1) * B // world
     shard = {k: v[lo:hi] for k, v in batch.items()}
+    ev, _ = st.eval_step(shard)                      # before any update: must equal the full-batch loss of the first train step
     outs = [st.train_step(shard) for _ in range(2)]  # noise=None: the rank slice of the global PRNGKey(0) draw
     if rank == 0:
       # single-process reference: the same TrainState code at world 1 semantics, full batch, global noise
@@ -151,7 +158,7 @@ def _ts_worker(rank, world, port, q):
         losses.append(float(ld['total_loss']))
         a1(flat, g, mm, vv, sched(step), step, 1.0, 0.9, 0.999, 1e-8, 0.01, sc)
       q.put((bcast_ok, float((st.flat - flat).abs().max()), [float(o['train/loss']) for o in outs], losses,
-             float(outs[-1]['train/grad_norm']), float(sc[0])))
+             float(outs[-1]['train/grad_norm']), float(sc[0]), float(ev['eval/loss'])))
     else:
       q.put((bcast_ok,))
   finally:
@@ -171,7 +178,8 @@ def test_trainstate_step_world2_equals_full_batch():
     assert p.exitcode == 0
   full = next(r for r in res if len(r) > 1)
   assert all(r[0] for r in res), 'rank-0 parameter broadcast at construction'
-  _, perr, losses, ref_losses, gn, gn_ref = full
+  _, perr, losses, ref_losses, gn, gn_ref, ev_loss = full
+  assert abs(ev_loss - ref_losses[0]) < 1e-5 * abs(ref_losses[0])  # eval_step: global denominator, losses summed over ranks
   assert perr < 2e-6, perr  # two AdamW steps on fp32 buffers; gradients differ only by summation order
   for a, b in zip(losses, ref_losses):
     assert abs(a - b) < 1e-5 * abs(b)

@@ -194,6 +194,30 @@ def test_train_step_matches_oracle_adamw(spa3d):
     assert max_abs(got[k], v) < 2e-4, k  # three Adam steps at lr 1e-2: sign-like updates amplify tiny grad differences
 
 
+def test_eval_step_matches_oracle_and_leaves_the_state_alone(spa3d):
+  """TrainState.eval_step (train.py:189-213): forward + compute_loss_3d on the current parameters, the reference's 'eval/...' metric
+  keys, predictions returned, nothing updated."""
+  cfg = O.Config(**MINI, use_dino=False, use_depth=False)
+  B, N, Q, T = 2, 6, 4, 8
+  model, params, batch, gb = _setup(spa3d, cfg, B, N, Q, T, 'fp32')
+  noise = _noise(B, cfg)
+  st = spa3d.TrainState(model, params, learning_rate=1e-2, warmup_steps=2, total_steps=10)
+  before = st.flat.clone()
+  metrics, preds = st.eval_step(gb, noise=noise.cuda())
+  assert sorted(metrics) == ['eval/loss', 'eval/position_loss', 'eval/visible_loss']
+  om = O.TrackAutoEncoder3D(cfg)
+  P = _params_to_oracle(params, torch.float64)
+  b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+  ref = om(P, b64, noise=noise.double())
+  ld = O.compute_loss_3d(ref, b64)
+  for k, r in (('eval/loss', 'total_loss'), ('eval/position_loss', 'position_loss'), ('eval/visible_loss', 'visible_loss')):
+    assert abs(float(metrics[k]) - float(ld[r])) < 1e-4 * abs(float(ld[r])), k
+  assert max_abs(preds.tracks, ref.tracks) < 1e-4 and max_abs(preds.visible_logits, ref.visible_logits) < 1e-4
+  assert torch.equal(st.flat, before) and st.step == 0
+  mt = st.train_step(gb, noise=noise.cuda())   # the same loss before the first update
+  assert abs(float(mt['train/loss']) - float(metrics['eval/loss'])) < 1e-5 * abs(float(metrics['eval/loss']))
+
+
 def test_cfg1_bf16_tiled_vs_generic_and_fp32(spa3d, monkeypatch):
   """Full-size model at cfg#1 shapes in bf16: the tiled MFMA GEMMs / fused kernels (default) against the generic
   kernels (SPA3D_GEMM_IMPL=1, SPA3D_ATTN_IMPL=1: same bf16 arithmetic, different accumulation order) and against
