@@ -901,7 +901,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
                               );
       }
     } else {          // ------------------------------------------------------------------ (b) key tiles -> dk, dv
-      for (int kt = w; kt < QTk; kt += 4) {  // real key tiles only
+      for (int kt = 3 - w; kt < QTk; kt += 4) {  // real key tiles only; dealt in the reverse wave order of role (a): with 9 or 10 tiles the SIMDs whose dQ wave has three tiles get a dK/dV wave with two
         const int k0 = kt * 16;
         int krow = k0 + fr; const bool valid = krow < Sk; if (!valid) krow = Sk - 1;
         u16x4 xraw[6];  // raw k row for the RMSNorm backward, requested before the MFMA work (see part (a))
