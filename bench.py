@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- train-step tracks/sec of the 3DSPA hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps K --warmup W [--config {1,2,3}]
+  python bench.py --gpus N --steps K --warmup W [--config {1,2,3}]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Called WITHOUT a torchrun environment and --gpus N > 1, bench.py starts the N ranks itself: before anything touches a GPU it runs
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same args>`
+as a CHILD process, relays its output and exits with its status.  A rank whose WORLD_SIZE differs from --gpus refuses to run.
+--launch-check: every rank joins a gloo group (no GPU call), proves the N-rank communicator with an all-reduce of ones, rank 0 prints
+one JSON line and all exit -- the launch path is testable on a CPU-only host (tests/test_bench_launch.py).
 
 One step = forward + compute_loss_3d + backward + (RCCL gradient all-reduce) + clip/AdamW over one synthetic
 batch resident in HBM.  Default workload at every N: BASELINE.json configs[2] per GPU (B=64, 2048 support + 512 query,
@@ -198,6 +204,39 @@ def gpu_same_shape(spa3d, dev):
   return out
 
 
+def spawn_ranks(n: int, argv) -> int:
+  """Start the n ranks of this same command under torch.distributed.run as a CHILD process (never an exec: the parent has not
+  touched the GPU and does not need to, but a child keeps that true by construction), relay its output, return its exit status."""
+  import socket
+  import subprocess
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+         '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+  print('bench.py: launching', ' '.join(cmd), file=sys.stderr, flush=True)
+  return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check(rank: int, world: int, gpus: int) -> int:
+  """No GPU call anywhere: gloo group over 127.0.0.1, all-reduce of ones must equal the world size."""
+  ok = True
+  if world > 1:
+    dist.init_process_group('gloo')
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    ok = int(t.item()) == world
+    dist.barrier()
+    dist.destroy_process_group()
+  if rank == 0:
+    print(json.dumps({'launch_check': bool(ok and world == gpus), 'n_gpus': world, 'ranks_verified': world if ok else 0,
+                      'requested_gpus': gpus, 'backend': 'gloo'}), flush=True)
+  return 0 if ok and world == gpus else 3
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -209,18 +248,31 @@ def main():
   ap.add_argument('--query', type=int, default=None)
   ap.add_argument('--frames', type=int, default=None)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--launch-check', action='store_true', help='prove the N-rank launch path over gloo and exit before any GPU call')
   args = ap.parse_args()
 
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:  # plain `python bench.py --gpus N`: start the ranks; nothing has touched a GPU
+    sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
   rank = int(os.environ.get('RANK', 0))
   local_rank = int(os.environ.get('LOCAL_RANK', 0))
   world = int(os.environ.get('WORLD_SIZE', 1))
   if world != args.gpus:
-    print(f'warning: WORLD_SIZE={world} but --gpus {args.gpus}', file=sys.stderr)
+    print(f'bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a number for a job of the wrong size', file=sys.stderr)
+    sys.exit(2)
+  if args.launch_check:
+    sys.exit(launch_check(rank, world, args.gpus))
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
+  rccl_ranks = 1
   if world > 1:
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     dist.init_process_group('nccl', device_id=dev)
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)  # the communicator really spans `world` ranks, each on its own GPU
+    rccl_ranks = int(ones.item())
+    if rccl_ranks != world:
+      print(f'bench.py: RCCL all-reduce of ones gave {rccl_ranks}, expected {world}', file=sys.stderr)
+      sys.exit(2)
 
   import spa3d
   cfg = dict(CONFIGS[args.config])
@@ -271,7 +323,7 @@ def main():
     C = 3 + depth + dino
     out = {
         'metric': f'train-step tracks/sec (B x N_tracks) at T={T}, C={C}', 'value': tracks / dt, 'unit': 'tracks/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True,
+        'n_gpus': world, 'rccl_ranks': rccl_ranks, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if precision == 'bf16' else 'f32', 'data': 'synthetic',
         'config': {'workload': cfg['name'] + ', fwd+loss+bwd+clip+AdamW' + (f' [overrides: B={B}, N={N}, Q={Q}, T={T}]' if (B, N, Q, T) != (cfg['B'], cfg['N'], cfg['Q'], cfg['T']) else ''),
                    'baseline_config': args.config, 'per_gpu_batch': B, 'global_batch': B * world, 'support': N, 'query': Q,
