@@ -1110,14 +1110,26 @@ template <typename T>
 __global__ __launch_bounds__(256) void share_reduce_kernel(const T* __restrict__ src, const int32_t* __restrict__ slot, const int32_t* __restrict__ slot_b,
                                                            int64_t nslot, int Q, int S, int d, T* __restrict__ dstU) {
   constexpr int NV = VecOf<T>::N;
-  extern __shared__ int32_t members[];  // [Q] + count
-  __shared__ int32_t nmem;
+  extern __shared__ int32_t members[];  // [Q]
+  __shared__ int32_t wcnt[4], nmem;
   const int64_t s_ = blockIdx.x; const int L = S - 1, cpr = d / NV;
   const int b = slot_b[s_];
-  if (threadIdx.x == 0) nmem = 0;
-  __syncthreads();
-  for (int q = threadIdx.x; q < Q; q += 256)
-    if (slot[(int64_t)b * Q + q] == (int32_t)s_) members[atomicAdd(&nmem, 1)] = q;
+  // member list in ascending query order (ballot + prefix, as prune_fill_kernel): the fp32 sums below then have ONE order, run to run
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int base = 0;
+  for (int q0 = 0; q0 < Q; q0 += 256) {
+    const int q = q0 + threadIdx.x;
+    const bool mine = q < Q && slot[(int64_t)b * Q + q] == (int32_t)s_;
+    const unsigned long long m = __ballot(mine);
+    if (lane == 0) wcnt[wv] = __popcll(m);
+    __syncthreads();
+    int pre = base;
+    for (int w2 = 0; w2 < wv; ++w2) pre += wcnt[w2];
+    if (mine) members[pre + __popcll(m & ((1ull << lane) - 1ull))] = q;
+    base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) nmem = base;
   __syncthreads();
   const int nm = nmem;
   for (int i = threadIdx.x; i < L * cpr; i += 256) {
@@ -1595,14 +1607,18 @@ void k_loss_bwd(spa3d_ctx* c, const float* head, int64_t nq, int T_, const float
 // Loss scale of the 16-bit backward (fp16 mode).  setting > 0: that value.  setting < 0: automatic -- the largest power of two that keeps
 // the head gradient's magnitude l1w / denom at or below |setting| (16): activations' gradients then sit mid-range in fp16 for any batch
 // size (at BASELINE cfg#3, denom = 4.4 M: 8192; a 100-element toy batch: 1).
-__global__ void set_loss_scale_kernel(const float* __restrict__ denom_dev, float l1w, float setting, float* __restrict__ scale_dev) {
+// `state` (may be null): the caller's dynamic-scale state, state[0] = a power-of-two multiplier in (0, 1] that spa3d_adamw_step halves after
+// a step with a non-finite gradient norm and grows back after 200 finite ones (0 or garbage-free zero memory = 1).
+__global__ void set_loss_scale_kernel(const float* __restrict__ denom_dev, float l1w, float setting, const float* __restrict__ state,
+                                      float* __restrict__ scale_dev) {
   float s = setting;
   if (setting < 0.f) s = fminf(fmaxf(exp2f(floorf(log2f(*denom_dev * (-setting) / l1w))), 1.f), 16777216.f);
+  if (state) { const float m = state[0]; if (m > 0.f && m < 1.f) s = fmaxf(s * m, 5.9604645e-8f); }
   *scale_dev = s;
 }
 void k_set_loss_scale(spa3d_ctx* c, const float* denom_dev, float l1w, float setting, float* scale_dev) {
   if (c->dry) return;
-  set_loss_scale_kernel<<<1, 1, 0, c->stream>>>(denom_dev, l1w, setting, scale_dev); SPA_LAUNCH_CHECK(c);
+  set_loss_scale_kernel<<<1, 1, 0, c->stream>>>(denom_dev, l1w, setting, c->loss_scale_state, scale_dev); SPA_LAUNCH_CHECK(c);
 }
 __global__ void unscale_kernel(float* __restrict__ a, const float* __restrict__ scale_dev, int64_t n) {
   const float s = 1.f / *scale_dev;
@@ -1631,6 +1647,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   const float gn = sqrtf(scratch[1]);
   const float sc = gn < clip ? 1.f : clip / gn;
   if (blockIdx.x == 0 && threadIdx.x == 0) scratch[0] = gn;
+  if (!(gn <= 3.0e38f)) return;  // inf / NaN gradient (an fp16 overflow): parameters and both moments stay as they are (adamw_guard_kernel reports it)
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float gi = g[i] * sc;
     float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -1641,11 +1658,23 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     p[i] = pi - lr * (mh / (sqrtf(vh) + eps) + wd * pi);
   }
 }
+// scratch[2] := 1 if this step was skipped (non-finite gradient norm) else 0; scratch[3] += skipped steps; scratch[4] = dynamic loss-scale
+// multiplier (0 = 1; halved on a skip, doubled up to 1 after 200 finite steps counted in scratch[5]) -- read by set_loss_scale_kernel when the
+// caller registered it with spa3d_set_loss_scale_state.
+__global__ void adamw_guard_kernel(float* scratch) {
+  const bool bad = !(sqrtf(scratch[1]) <= 3.0e38f);
+  scratch[2] = bad ? 1.f : 0.f;
+  float m = scratch[4]; if (!(m > 0.f && m <= 1.f)) m = 1.f;
+  if (bad) { scratch[3] += 1.f; m = fmaxf(m * 0.5f, 5.9604645e-8f); scratch[5] = 0.f; }
+  else if (m < 1.f) { scratch[5] += 1.f; if (scratch[5] >= 200.f) { m = fminf(2.f * m, 1.f); scratch[5] = 0.f; } }
+  scratch[4] = m;
+}
 void k_adamw(spa3d_ctx* c, float* p, const float* g, float* m, float* v, int64_t n, float lr, int64_t step, float clip, float b1, float b2,
              float eps, float wd, float* scratch) {
-  (void)hipMemsetAsync(scratch, 0, 16, c->stream);
+  (void)hipMemsetAsync(scratch, 0, 12, c->stream);
   unsigned gr = (unsigned)std::min<int64_t>(cdiv(n, 256), 4096);
   sumsq_kernel<<<gr, 256, 0, c->stream>>>(g, n, scratch + 1);
+  adamw_guard_kernel<<<1, 1, 0, c->stream>>>(scratch);
   double t = (double)(step + 1);
   float bc1 = (float)(1.0 - pow((double)b1, t)), bc2 = (float)(1.0 - pow((double)b2, t));
   adamw_kernel<<<gr, 256, 0, c->stream>>>(p, g, m, v, n, lr, bc1, bc2, clip, b1, b2, eps, wd, scratch);

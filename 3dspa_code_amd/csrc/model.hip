@@ -423,6 +423,7 @@ template <typename T> struct Net {
     if (can_prune) {
       int32_t* cnt = alloc<int32_t>(nseq); int32_t* off = alloc<int32_t>(nseq + 1); k.row_src = alloc<int32_t>(nseq * S);
       const int64_t kept = k_prune_plan(c, k.km, nseq, S, cnt, off, k.row_src);
+      if (!c->dry) { c->plan_stats[0] += (double)kept; c->plan_stats[1] += (double)(nseq * S); }
       if (c->dry || kept < nseq * S) { k.enc_rg.off = off; k.enc_rg.rows = kept; }   // (the sizing dry run takes this branch at the dense count)
     }
     const Rag& rg = k.enc_rg;
@@ -535,6 +536,7 @@ template <typename T> struct Net {
       if (c->dry) { sh.nslot = (int64_t)(SHARE_MAX_FRAC * (double)nq); sh.probe = true; k.ro_share = true; }
       else {
         sh.nslot = k_share_plan(c, k.qframe, k.Bc, k.Q, slot, slot_b, slot_f, slot_q0, scratch);
+        c->plan_stats[2] += (double)sh.nslot; c->plan_stats[3] += (double)nq;
         if ((double)sh.nslot <= SHARE_MAX_FRAC * (double)nq) {
           T* xU = alloc<T>(((sh.rows(nq, S) + 7) & ~int64_t(7)) * dd);
           k_share_assemble<T>(c, k.qtok, k.latd, slot_b, slot_f, sh.nslot, nq, L, Cl, dd, xU);
@@ -828,6 +830,7 @@ static int run(spa3d_ctx* c, RunArgs a, void* ws, int64_t ws_bytes, void* stream
     if (dry_need(c, a, mid) <= ws_bytes) lo = mid; else hi = mid - 1;
   }
   c->ar = Arena(); c->ar.base = (char*)ws; c->ar.cap = ws_bytes; c->dry = false;
+  for (double& v : c->plan_stats) v = 0;
   run_dispatch(c, a, lo);
   if (c->ar.overflow) { c->err = "internal: arena overflow"; return SPA3D_ERR_WORKSPACE; }
   if (c->hip_err) return SPA3D_ERR_HIP;
@@ -934,6 +937,29 @@ int spa3d_loss(spa3d_handle h, const spa3d_batch* b, const spa3d_outputs* preds,
   k_loss_from_preds(h, preds->tracks, preds->visible_logits, n, b->query_tracks, b->query_tracks_visible, scratch, h->cfg.model_kind == 1 ? 2 : 3);
   k_loss_finalize(h, scratch, scratch + 4, L1_WEIGHT, BCE_WEIGHT, loss3);
   return h->hip_err ? SPA3D_ERR_HIP : SPA3D_OK;
+}
+
+int spa3d_set_option(spa3d_handle h, const char* name, double value) {
+  if (!h || !name) return SPA3D_ERR_ARG;
+  const std::string n(name);
+  if (n == "prune") h->prune = value != 0;
+  else if (n == "ro_share") h->ro_share = value != 0;
+  else if (n == "loss_scale") { if (h->cfg.precision != SPA3D_F16) { h->err = "loss_scale applies to SPA3D_F16 handles only"; return SPA3D_ERR_ARG; } h->loss_scale = (float)value; }
+  else if (n == "attn_bwd_mode") h->attn_bwd_mode = (int)value;
+  else if (n == "attn_impl") h->attn_impl = (int)value;
+  else if (n == "gemm_impl") h->gemm_impl = (int)value;
+  else { h->err = "unknown option: " + n; return SPA3D_ERR_ARG; }
+  return SPA3D_OK;
+}
+int spa3d_set_loss_scale_state(spa3d_handle h, const float* state) {
+  if (!h) return SPA3D_ERR_ARG;
+  h->loss_scale_state = state;
+  return SPA3D_OK;
+}
+int spa3d_plan_stats(spa3d_handle h, double* out4) {
+  if (!h || !out4) return SPA3D_ERR_ARG;
+  for (int i = 0; i < 4; ++i) out4[i] = h->plan_stats[i];
+  return SPA3D_OK;
 }
 
 int spa3d_prof_enable(spa3d_handle h, int32_t on) {

@@ -166,8 +166,13 @@ def _ext_hook(code, data):
 def _unchunk(tree):
   if isinstance(tree, dict):
     if tree.get('__msgpack_chunked_array__'):
-      chunks = [tree['chunks'][str(i)] for i in range(len(tree['chunks']))]
-      return np.concatenate([c.reshape(-1) for c in chunks]).reshape(tuple(tree['shape']))
+      # Flax writes both 'chunks' and 'shape' through _tuple_to_dict: {'0': .., '1': ..} with str keys (a plain list is accepted too).
+      # Only the unchunked case has a round-trip here (msgpack_serialize refuses > 2**30-byte arrays); this branch is exercised by a
+      # hand-built fixture (tests/test_data_host.py); parity unpinned: no Flax here, no msgpack file in the reference.
+      def seq(v):
+        return [v[str(i)] for i in range(len(v))] if isinstance(v, dict) else list(v)
+      chunks = seq(tree['chunks'])
+      return np.concatenate([np.asarray(c).reshape(-1) for c in chunks]).reshape(tuple(int(x) for x in seq(tree['shape'])))
     return {k: _unchunk(v) for k, v in tree.items()}
   return tree
 

@@ -68,8 +68,9 @@ def broadcast_state_(tensors, src: int = 0, group=None, force=False):
   (a checkpoint read on rank 0 only, different seeds): one broadcast per buffer at construction / resume."""
   if not _collectives_on(group, force):
     return
+  gsrc = dist.get_global_rank(group, src) if group is not None else src  # dist.broadcast takes a GLOBAL rank; `src` is a rank of `group`
   for t in tensors:
-    dist.broadcast(t, src=src, group=group)
+    dist.broadcast(t, src=gsrc, group=group)
 
 
 def _hip_uniform_noise(n: int, device) -> torch.Tensor:
@@ -120,6 +121,11 @@ class TrainState:
     self._noise_fn = noise_fn or _hip_uniform_noise
     self._evaluate = evaluate or self._hip_evaluate
     self._noise_cache = {}
+    if model.precision == 'fp16' and compute is None and adamw is None:
+      # dynamic loss scale: spa3d_adamw_step skips a step whose gradient norm is inf/NaN and halves the multiplier kept in scratch[4],
+      # which the next spa3d_loss_and_grads on this handle applies (include/spa3d.h)
+      h = model._handle(*model._dims_from_params(self.params))[0]
+      _lib.check(_lib.load().spa3d_set_loss_scale_state(h, self.scratch.data_ptr() + 16), h, 'spa3d_set_loss_scale_state')
     self.sync_from_rank0()
 
   def sync_from_rank0(self):
@@ -147,6 +153,12 @@ class TrainState:
     r*B_local .. of that tensor, not a draw of its own over [B_local, L, Ld].  Fixed key => drawn once and cached."""
     key = (b_local, self.world, self.rank)
     if key not in self._noise_cache:
+      if self.world > 1:  # the slice arithmetic below needs the same local batch on every rank
+        sizes = torch.tensor([b_local, -b_local], dtype=torch.int64, device=self.flat.device)
+        dist.all_reduce(sizes, op=dist.ReduceOp.MAX, group=self.pg)
+        if int(sizes[0]) != b_local or int(-sizes[1]) != b_local:
+          raise ValueError(f'rank {self.rank}: local batch {b_local} differs across ranks (max {int(sizes[0])}, min {int(-sizes[1])}); '
+                           'the global discretisation noise is sliced by equal per-rank batches')
       L, Ld = self.model.num_latent_tokens, self.model.latent_token_dim
       full = self._noise_fn(b_local * self.world * L * Ld, self.flat.device).view(self.world, b_local, L, Ld)
       self._noise_cache = {key: full[self.rank].clone()}
@@ -166,8 +178,9 @@ class TrainState:
     self._adamw(self.flat, self.grads, self.m, self.v, lr, self.step, self.clip, self.b1, self.b2, self.eps, self.wd, self.scratch)
     self.step += 1
     # metric keys of train.py:180-185 (device scalars)
+    # 'train/skipped' = 1 when the update was skipped (non-finite gradient norm: fp16 overflow), 'train/loss_scale_mult' the dynamic multiplier
     return {'train/loss': l3[0], 'train/position_loss': l3[1], 'train/visible_loss': l3[2], 'train/learning_rate': lr,
-            'train/grad_norm': self.scratch[0]}
+            'train/grad_norm': self.scratch[0], 'train/skipped': self.scratch[2], 'train/loss_scale_mult': self.scratch[4]}
 
   def eval_step(self, batch, discretize: bool = True, noise=None):
     """train.py:189-213: forward pass + compute_loss on the current parameters, no update.  Returns (metrics, predictions) with the

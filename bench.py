@@ -311,6 +311,11 @@ def main():
     lib.spa3d_prof_enable(h, 0)
     if r is not None:
       roof, mfma_flops = r
+  # the two data-dependent savings the step time rests on: fraction of track-encoder token rows kept by the pruning, and distinct
+  # (sample, query frame) slots per query of the shared readout rows -- at this synthetic distribution (Bernoulli(0.9) visibility, uniform frames)
+  ps = (spa3d._lib.C.c_double * 4)()
+  lib.spa3d_plan_stats(h, ps)
+  plan = {'encoder_rows_kept_fraction': round(ps[0] / ps[1], 4) if ps[1] else 1.0, 'readout_slots_per_query': round(ps[2] / ps[3], 4) if ps[3] else 1.0}
   tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
   if world > 1:
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -328,7 +333,7 @@ def main():
         'config': {'workload': cfg['name'] + ', fwd+loss+bwd+clip+AdamW' + (f' [overrides: B={B}, N={N}, Q={Q}, T={T}]' if (B, N, Q, T) != (cfg['B'], cfg['N'], cfg['Q'], cfg['T']) else ''),
                    'baseline_config': args.config, 'per_gpu_batch': B, 'global_batch': B * world, 'support': N, 'query': Q,
                    'frames': T, 'channels': C, 'parallelism': f'dp{world}', 'chunk_samples': int(os.environ.get('SPA3D_CHUNK', 0)),
-                   'final_loss': loss},
+                   'final_loss': loss, **plan},
         'roofline': roof,
     }
     if args.config in F_REF_FWD_PER_STEP_B64:

@@ -138,10 +138,29 @@ int spa3d_loss_and_grads(spa3d_handle h, const float* params, const spa3d_batch*
 
 /* clip_by_global_norm(clip) -> adamw(b1,b2,eps,wd) -> apply_updates on flat buffers, in place.
  * step = optimizer count BEFORE this update (bias correction uses step+1).
- * scratch: >= 4 KiB device; scratch[0] returns the global grad norm. */
+ * scratch: >= 4 KiB device, zero-initialised once by the caller and then left alone between steps: scratch[0] returns the global grad norm,
+ * [1] is internal, [2] = 1 when THIS step was skipped because the norm was inf/NaN (an fp16 overflow; params, m, v unchanged) else 0,
+ * [3] counts skipped steps, [4] / [5] hold the dynamic loss-scale multiplier and its good-step counter (spa3d_set_loss_scale_state). */
 int spa3d_adamw_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr,
                      int64_t step, float clip, float b1, float b2, float eps, float wd,
                      float* scratch, void* stream);
+
+/* Per-handle switches (the same ones the SPA3D_* environment variables preset at spa3d_create): "prune" (token pruning of the track
+ * encoder, 0/1), "ro_share" (shared latent rows of the first readout block, 0/1) -- with both 0 every entry point is fully asynchronous
+ * (no plan count is read back) --, "loss_scale" (SPA3D_F16 handles: > 0 fixed, < 0 automatic with that head-gradient target),
+ * "attn_bwd_mode", "attn_impl", "gemm_impl" (diagnostics).  Unknown names return SPA3D_ERR_ARG. */
+int spa3d_set_option(spa3d_handle h, const char* name, double value);
+
+/* Dynamic loss scaling of the SPA3D_F16 backward.  `state` (device, caller-owned, may be NULL to detach) is one float: a power-of-two
+ * multiplier in (0,1] applied on top of the per-call scale (0 reads as 1).  Point it at scratch + 4 of spa3d_adamw_step: that call skips the
+ * update when the gradient norm is not finite (parameters and moments untouched), halves the multiplier, and doubles it back (up to 1)
+ * after 200 finite steps. */
+int spa3d_set_loss_scale_state(spa3d_handle h, const float* state);
+
+/* Data-dependent plan sizes of the last spa3d_loss_and_grads / forward call on this handle, summed over its sample chunks:
+ * out4 = {track-encoder token rows kept, token rows before pruning, distinct (sample, query frame) slots, queries}; zeros when the
+ * respective saving is off.  Host values (they are the counts the call read back to size its launches). */
+int spa3d_plan_stats(spa3d_handle h, double* out4);
 
 /* Live timing of the hot kernel classes with HIP event pairs recorded on the launch stream (bench.py's
  * "roofline" object).  cls: 0 tiled NT GEMM, 1 tiled TN GEMM (dW), 2 generic GEMM, 3 fused attention fwd,

@@ -115,6 +115,15 @@ def test_flax_msgpack_checkpoint_reader(spa3d, tmp_path):
   import msgpack
   bf = msgpack.ExtType(1, msgpack.packb(([2], 'bfloat16', np.array([0x3f80, 0xc000], np.uint16).tobytes()), use_bin_type=True))
   assert D.msgpack_restore(msgpack.packb({'w': bf}, use_bin_type=True))['w'].tolist() == [1.0, -2.0]
+  # chunked array as Flax writes it (> 2**30-byte leaves): 'chunks' AND 'shape' go through _tuple_to_dict -> str-keyed dicts.  Hand-built.
+  def nd(a):
+    return msgpack.ExtType(1, msgpack.packb((list(a.shape), a.dtype.name, a.tobytes()), use_bin_type=True))
+  whole = np.arange(12, dtype=np.float32).reshape(3, 4)
+  chunked = {'__msgpack_chunked_array__': True, 'shape': {'0': 3, '1': 4}, 'chunks': {'0': nd(whole.reshape(-1)[:5]), '1': nd(whole.reshape(-1)[5:])}}
+  got_c = D.msgpack_restore(msgpack.packb({'big': chunked}, use_bin_type=True))['big']
+  assert got_c.shape == (3, 4) and np.array_equal(got_c, whole)
+  chunked['shape'] = [3, 4]  # a plain list is accepted too
+  assert np.array_equal(D.msgpack_restore(msgpack.packb({'big': chunked}, use_bin_type=True))['big'], whole)
   cfg = O.Config(**MINI, use_dino=True, use_depth=True, dino_feature_dim=6, depth_feature_dim=2)
   p = O.init_params(cfg, seed=3, depth_dim=2)
   pn = O.tree_map(lambda v: v.numpy(), p)

@@ -64,7 +64,9 @@ def test_dp2_gradients_equal_full_batch():
     p.start()
   for p in procs:
     p.join(300)
-    assert p.exitcode == 0
+    if p.is_alive():
+      p.kill()
+    assert p.exitcode == 0, f'worker exit code {p.exitcode}'
   err, scale, loss, loss_ref, denom, vis = q.get()
   assert denom == vis  # global count, identical on every rank
   assert err < 1e-9 * max(1.0, scale)
@@ -172,10 +174,12 @@ def test_trainstate_step_world2_equals_full_batch():
   procs = [ctx.Process(target=_ts_worker, args=(r, 2, port, q)) for r in range(2)]
   for p in procs:
     p.start()
-  res = [q.get(), q.get()]
-  for p in procs:
+  for p in procs:  # join with a timeout and check the exit codes BEFORE draining the queue: a crashed worker must fail, not hang, the suite
     p.join(300)
-    assert p.exitcode == 0
+    if p.is_alive():
+      p.kill()
+    assert p.exitcode == 0, f'worker exit code {p.exitcode}'
+  res = [q.get(), q.get()]
   full = next(r for r in res if len(r) > 1)
   assert all(r[0] for r in res), 'rank-0 parameter broadcast at construction'
   _, perr, losses, ref_losses, gn, gn_ref, ev_loss = full

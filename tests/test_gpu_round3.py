@@ -1,0 +1,170 @@
+"""Round-3 parity cases on the GPU (all through the C-ABI):
+  * ONE FULL-WIDTH chunked batch at the benchmark's own width (N = 2048 support + Q = 512 query tracks, T = 150, C = 772), default bf16 dispatch
+    (token pruning, shared readout rows, persistent multi-round tile lists, TN split-M at ~0.6 M rows, a ragged last chunk) against the
+    library's fp32 parity mode on the same inputs (track_autoencoder_3d.py:151-188,276-285);
+  * fp16 overflow: a step whose gradient norm is inf/NaN is skipped (parameters and moments untouched) and halves the dynamic loss scale;
+  * fp16 shared readout rows with EVERY query of a sample on one frame at Q = 512 (the TAPVid 'first'-query layout);
+  * bf16 vs fp32 gradients at each of 30 parameter states along the fp32 training trajectory (not chaotic, unlike two separate trainings).
+PARITY UNPINNED: the fp32 parity mode is itself checked against this repo's fp64 oracle (tests/test_gpu_t150.py), not against
+the reference, which cannot run."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from util import O, batch_to, product_model, rel_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_full_width_sample_bf16_default_dispatch_vs_fp32_parity_mode(monkeypatch):
+  import spa3d
+  import bench  # synthetic-input recipe of the benchmark; nothing is timed here
+  B, N, Q, T = 3, 2048, 512, 150
+  monkeypatch.setenv('SPA3D_CHUNK', '2')  # chunks of 2 and 1 samples: the ragged last chunk of the bench (64 = 7 x 9 + 1)
+  dev = torch.device('cuda', 0)
+  batch = bench.synth_batch(B, N, Q, T, 768, 1, dev, seed=99, feat_dtype=torch.bfloat16)
+  noise = torch.rand(B, 128, 96, generator=torch.Generator().manual_seed(5)).to(dev)
+  runs = {}
+  stats = None
+  for precision in ('bf16', 'fp32'):
+    model = spa3d.TrackAutoEncoder3D(num_output_frames=T, dino_feature_dim=768, depth_feature_dim=1, precision=precision)
+    params = model.init(0, batch)['params']
+    b = dict(batch)
+    if precision == 'fp32':
+      b['dino_features'] = batch['dino_features'].float(); b['depth_features'] = batch['depth_features'].float()
+    ld, grads, preds = model.loss_and_grads({'params': params}, b, noise=noise, return_predictions=True)
+    torch.cuda.synchronize()
+    if precision == 'bf16':
+      o = (spa3d._lib.C.c_double * 4)()
+      spa3d._lib.check(spa3d._lib.load().spa3d_plan_stats(model._handle(768, 1)[0], o))
+      stats = list(o)
+    runs[precision] = ([float(ld[k]) for k in ('total_loss', 'position_loss', 'visible_loss')], {k: v.clone() for k, v in O.tree_flatten(grads).items()},
+                       preds.tracks.clone(), preds.visible_logits.clone())
+    del model, params, grads, preds
+    torch.cuda.empty_cache()
+  (l16, g16, t16, v16), (l32, g32, t32, v32) = runs['bf16'], runs['fp32']
+  print(f'full width: plan stats kept/dense rows {stats[0]:.0f}/{stats[1]:.0f} = {stats[0] / stats[1]:.3f}, slots/queries {stats[2]:.0f}/{stats[3]:.0f} = {stats[2] / stats[3]:.3f}')
+  assert 0.85 < stats[0] / stats[1] < 0.95 and 0.2 < stats[2] / stats[3] < 0.45  # the pruned and shared paths ran, at the bench's data distribution
+  e_t, e_v = rel_err(t16, t32), rel_err(v16, v32)
+  print(f'full width bf16 vs fp32: tracks rel {e_t:.3e} logits rel {e_v:.3e} losses {l16} vs {l32}')
+  assert e_t < 2e-2 and e_v < 5e-2
+  assert abs(l16[0] - l32[0]) < 5e-3 * abs(l32[0]) and abs(l16[1] - l32[1]) < 5e-3 * abs(l32[1])
+  names = sorted(g32)
+  worst = ('', 0.0)
+  for k in names:
+    n32 = float(g32[k].double().norm())
+    e = rel_err(g16[k], g32[k]) if n32 > 1e-12 else float(g16[k].abs().max())
+    if e > worst[1]:
+      worst = (k, e)
+    assert e < 0.20, (k, e)
+    assert bool(torch.isfinite(g16[k]).all())
+  a = torch.cat([g16[k].double().reshape(-1) for k in names]); b_ = torch.cat([g32[k].double().reshape(-1) for k in names])
+  cos = float((a @ b_) / (a.norm() * b_.norm()))
+  print(f'full width: worst bf16-vs-fp32 gradient leaf {worst}, whole-gradient cosine {cos:.5f}')
+  assert cos > 0.999
+
+
+def _small_full_model_case(B=2, N=8, Q=16, T=24, seed=31):
+  cfg = O.Config(num_output_frames=T, use_dino=True, use_depth=True, dino_feature_dim=768, depth_feature_dim=1)
+  batch = O.synthetic_batch(B, N, Q, T, seed=seed, dino_dim=768, depth_dim=1)
+  noise = torch.rand(B, cfg.num_latent_tokens, cfg.latent_token_dim, generator=torch.Generator().manual_seed(3))
+  return cfg, batch, noise
+
+
+@pytest.mark.gpu
+def test_fp16_overflow_skips_the_update_and_halves_the_scale():
+  import spa3d
+  cfg, batch, noise = _small_full_model_case()
+  gb = batch_to(batch, 'cuda')
+  for k in ('dino_features', 'depth_features'):
+    gb[k] = gb[k].half()
+  model = product_model(spa3d, cfg, 'fp16')
+  st = spa3d.TrainState(model, model.init(0, gb)['params'], learning_rate=1e-3, warmup_steps=0, total_steps=100)
+  lib = spa3d._lib.load()
+  h = model._handle(768, 1)[0]
+  m0 = st.train_step(gb, noise=noise.cuda())
+  assert float(m0['train/skipped']) == 0.0 and np.isfinite(float(m0['train/grad_norm'])) and float(m0['train/loss_scale_mult']) == 1.0
+  before = (st.flat.clone(), st.m.clone(), st.v.clone())
+  spa3d._lib.check(lib.spa3d_set_option(h, b'loss_scale', 1e9), h)  # forces an fp16 overflow in the 16-bit backward
+  m1 = st.train_step(gb, noise=noise.cuda())
+  torch.cuda.synchronize()
+  print('forced overflow: grad norm', float(m1['train/grad_norm']), 'skipped', float(m1['train/skipped']), 'mult', float(m1['train/loss_scale_mult']))
+  assert float(m1['train/skipped']) == 1.0 and not np.isfinite(float(m1['train/grad_norm']))
+  assert torch.equal(st.flat, before[0]) and torch.equal(st.m, before[1]) and torch.equal(st.v, before[2])
+  assert float(m1['train/loss_scale_mult']) == 0.5
+  spa3d._lib.check(lib.spa3d_set_option(h, b'loss_scale', -16.0), h)  # back to the automatic scale (now times the halved multiplier)
+  m2 = st.train_step(gb, noise=noise.cuda())
+  assert float(m2['train/skipped']) == 0.0 and np.isfinite(float(m2['train/grad_norm']))
+  assert not torch.equal(st.flat, before[0]) and bool(torch.isfinite(st.flat).all())
+  assert abs(float(m2['train/grad_norm']) - float(m0['train/grad_norm'])) < 0.5 * float(m0['train/grad_norm'])  # true-scale gradients again
+  assert lib.spa3d_set_option(h, b'no_such_option', 1.0) == 1
+
+
+@pytest.mark.gpu
+def test_fp16_shared_rows_every_query_on_one_frame_q512():
+  """All 512 queries of every sample share ONE frame: one slot per sample, each pre-summed dqkv row is a sum over 512 members at loss-scale
+  magnitude (kept in fp32 until the single 16-bit rounding)."""
+  import spa3d
+  cfg, batch, noise = _small_full_model_case(B=2, N=8, Q=512, T=24, seed=77)
+  qp = batch['query_points'].clone()
+  qp[0, :, 0] = 3.0; qp[1, :, 0] = 23.0
+  batch['query_points'] = qp
+  gb = batch_to(batch, 'cuda')
+  for k in ('dino_features', 'depth_features'):
+    gb[k] = gb[k].half()
+  lib = spa3d._lib.load()
+  runs = {}
+  for share in (1, 0):
+    model = product_model(spa3d, cfg, 'fp16')
+    params = model.init(0, gb)['params']
+    h = model._handle(768, 1)[0]
+    spa3d._lib.check(lib.spa3d_set_option(h, b'ro_share', float(share)), h)
+    ld, grads, preds = model.loss_and_grads({'params': params}, gb, noise=noise.cuda(), return_predictions=True)
+    torch.cuda.synchronize()
+    o = (spa3d._lib.C.c_double * 4)()
+    lib.spa3d_plan_stats(h, o)
+    runs[share] = (float(ld['total_loss']), {k: v.clone() for k, v in O.tree_flatten(grads).items()}, preds.tracks.clone(), list(o))
+  assert runs[1][3][2] == 2.0 and runs[1][3][3] == 1024.0 and runs[0][3][3] == 0.0  # two slots for 1024 queries; off: no plan
+  d_t = rel_err(runs[1][2], runs[0][2])
+  worst = max((rel_err(runs[1][1][k], runs[0][1][k]), k) for k in runs[0][1] if float(runs[0][1][k].double().norm()) > 1e-12)
+  print(f'fp16 Q=512 one frame per sample, shared vs dense: tracks {d_t:.3e}, worst gradient leaf {worst}')
+  assert all(bool(torch.isfinite(v).all()) for v in runs[1][1].values())
+  assert d_t < 1e-3 and worst[0] < 3e-2 and abs(runs[1][0] - runs[0][0]) < 1e-3 * abs(runs[0][0])
+
+
+@pytest.mark.gpu
+def test_bf16_gradients_agree_with_fp32_along_the_fp32_trajectory():
+  """At each of 30 parameter states of an fp32 training run (full-size model, BASELINE cfg#1's shape + DINO/depth), the bf16 gradient of the
+  SAME parameters and batch against the fp32 one: whole-vector cosine and every leaf's relative error.  Unlike two separate trainings this
+  is not chaotic: it bounds what bf16 activations do to one step."""
+  import spa3d
+  cfg = O.Config(num_output_frames=24, use_dino=True, use_depth=True, dino_feature_dim=768, depth_feature_dim=1)
+  B, N, Q, T = 2, 64, 16, 24
+  batch = O.synthetic_batch(B, N, Q, T, seed=1234, dino_dim=768, depth_dim=1)
+  gb = batch_to(batch, 'cuda')
+  noise = torch.rand(B, cfg.num_latent_tokens, cfg.latent_token_dim, generator=torch.Generator().manual_seed(0)).cuda()
+  b32 = dict(gb); b16 = dict(gb)
+  for k in ('dino_features', 'depth_features'):
+    b16[k] = gb[k].bfloat16(); b32[k] = gb[k].bfloat16().float()
+  m32 = product_model(spa3d, cfg, 'fp32'); m16 = product_model(spa3d, cfg, 'bf16')
+  st = spa3d.TrainState(m32, m32.init(0, gb)['params'], learning_rate=3e-4, warmup_steps=5, total_steps=60)
+  cos_min, worst = 1.0, (0.0, '', -1)
+  for step in range(30):
+    _, g32, _ = m32.loss_and_grads({'params': st.params}, b32, noise=noise)
+    _, g16, _ = m16.loss_and_grads({'params': st.params}, b16, noise=noise)
+    a, b_ = g16.flat.double(), g32.flat.double()
+    cos_min = min(cos_min, float((a @ b_) / (a.norm() * b_.norm())))
+    f16, f32 = O.tree_flatten(g16), O.tree_flatten(g32)
+    for k in f32:
+      if float(f32[k].double().norm()) > 1e-12:
+        e = rel_err(f16[k], f32[k])
+        if e > worst[0]:
+          worst = (e, k, step)
+    st.train_step(b32, noise=noise)
+  print(f'bf16 vs fp32 gradients over 30 fp32 states: min cosine {cos_min:.6f}, worst leaf {worst}')
+  assert cos_min >= 0.999
+  assert worst[0] <= 0.10, worst
