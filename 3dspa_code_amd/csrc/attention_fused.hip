@@ -51,6 +51,16 @@ __device__ __forceinline__ uint2 lds_tr16_b64_o(const void* p) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
   return v;
 }
+// 16-byte LDS read the COMPILER DOES NOT TRACK (no s_waitcnt of its own): for hand-sequenced loops that keep several groups of reads in flight
+// and retire them with counted s_waitcnt lgkmcnt(N) (LDS operations return in order)
+template <int OFF>
+__device__ __forceinline__ uint4 lds_b128_o(const void* p) {
+  static_assert(OFF >= 0 && OFF < 65536, "16-bit DS offset");
+  uint4 v;
+  const unsigned a = (unsigned)(uintptr_t)p;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+  return v;
+}
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
@@ -562,7 +572,10 @@ struct AttnBwdArgs {
 // the row's (max, log-sum, delta); xraw: the raw q row in the accumulator layout (d = 16dt + 4fq + r) for the RMSNorm backward.
 // X (cross attention): the tile's dQ^ rows go out as fp32 partials (dqp: row 0 of the tile, 96 floats per row) -- the sum over key chunks and
 // the RMSNorm backward happen in xattn_dq_finish_kernel; xraw / wt / gtile / ds_acc are unused.
-template <int KT, bool X = false>
+// FAST (no key mask, self attention): the row constants ride in the accumulators' initial value -- mq = -(m + l) / alpha, dq_ = -delta -- so a score
+// element costs fma + exp2 + mul + half a conversion instead of ~13 VALU operations, and alpha is applied once to the fp32 dQ^ sums.  Padding
+// keys (kbias = -inf) still give P = 0 exactly.  With a mask the finfo.min semantics (fully-masked rows attend uniformly) need the reference's order.
+template <int KT, bool X = false, bool FAST = false>
 __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, const float* kbias, const float* scq,
                                                const mfma16x8 (&qb)[3], const mfma16x8 (&dob)[3], float mq, float lq, float dq_,
                                                const u16x4 (&xraw)[6], bool valid, char* wt, bf16_t* gtile, int64_t ld_, int nrows,
@@ -587,6 +600,7 @@ __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, c
     for (int hf = 0; hf < 2; ++hf) {
       const int kt = 2 * s2 + hf;
       f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (FAST) { st = f32x4{mq, mq, mq, mq}; dpt = f32x4{dq_, dq_, dq_, dq_}; }
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         const mfma16x8 kf = *(const mfma16x8*)(Ks + kt * ROW16 + row_off(fr) + (s * 32 + fq * 8) * 2);
@@ -597,9 +611,14 @@ __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, c
       const f32x4 b4 = *(const f32x4*)(kbias + kt * 16 + fq * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = __expf((st[r] * alpha + b4[r] - mq) - lq);
-        const float ds = (b4[r] == 0.f) ? p * (dpt[r] - dq_) * alpha : 0.f;  // where() passes no gradient to masked logits
-        t[hf * 4 + r] = f2bf(ds);
+        if constexpr (FAST) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(st[r], 0.10206207261596575f * 1.4426950408889634f, b4[r]));  // b4: 0 or -inf
+          t[hf * 4 + r] = f2bf(p * dpt[r]);
+        } else {
+          const float p = __expf((st[r] * alpha + b4[r] - mq) - lq);
+          const float ds = (b4[r] == 0.f) ? p * (dpt[r] - dq_) * alpha : 0.f;  // where() passes no gradient to masked logits
+          t[hf * 4 + r] = f2bf(ds);
+        }
       }
     }
     dsb[s2] = __builtin_bit_cast(mfma16x8, t);
@@ -637,7 +656,7 @@ __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, c
   for (int dt = 0; dt < 6; ++dt) {
     const u16x4 xv = xraw[dt];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { x[dt][r] = bf2f(xv[r]); ss += x[dt][r] * x[dt][r]; }
+    for (int r = 0; r < 4; ++r) { x[dt][r] = bf2f(xv[r]); ss += x[dt][r] * x[dt][r]; if constexpr (FAST) dqa[dt][r] *= alpha; }
   }
   ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
   const float rr = rsqrtf(ss / DH + 1e-6f);
@@ -666,7 +685,7 @@ __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, c
 
 // (b) one 16-key tile against all queries.  kb / vb: this lane's key row as B-operand fragments (k^ normalised, v raw); kbv: its
 // key bias; xraw: the raw k row in the accumulator layout.
-template <int KT>
+template <int KT, bool FAST = false>  // FAST: as bwd_query_tile -- mrow holds -(m + l) / alpha, drow holds -delta, lrow is unused
 __device__ __forceinline__ void bwd_key_tile(const char* Qs, const char* dOs, const float* mrow, const float* lrow,
                                              const float* drow, const float* sck, const mfma16x8 (&kb)[3], const mfma16x8 (&vb)[3],
                                              float kbv, const u16x4 (&xraw)[6], bool valid, char* wt, bf16_t* gk, int64_t ldk_, bf16_t* gv,
@@ -684,6 +703,7 @@ __device__ __forceinline__ void bwd_key_tile(const char* Qs, const char* dOs, co
     for (int hf = 0; hf < 2; ++hf) {
       const int qt = 2 * s2 + hf;
       f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (FAST) { st = *(const f32x4*)(mrow + qt * 16 + fq * 4); dpt = *(const f32x4*)(drow + qt * 16 + fq * 4); }
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         const mfma16x8 qf = *(const mfma16x8*)(Qs + qt * ROW16 + row_off(fr) + (s * 32 + fq * 8) * 2);
@@ -691,14 +711,23 @@ __device__ __forceinline__ void bwd_key_tile(const char* Qs, const char* dOs, co
         st = MFMA16(qf, kb[s], st);     // S[q = 16qt+4fq+r][key = k0+fr]
         dpt = MFMA16(df, vb[s], dpt);   // dP[q][key]
       }
-      const f32x4 m4 = *(const f32x4*)(mrow + qt * 16 + fq * 4);
-      const f32x4 l4 = *(const f32x4*)(lrow + qt * 16 + fq * 4);
-      const f32x4 d4 = *(const f32x4*)(drow + qt * 16 + fq * 4);
+      if constexpr (FAST) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __expf((st[r] * alpha + kbv - m4[r]) - l4[r]);
-        tp_[hf * 4 + r] = f2bf(p);
-        tds[hf * 4 + r] = f2bf(keep ? p * (dpt[r] - d4[r]) * alpha : 0.f);
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(st[r], 0.10206207261596575f * 1.4426950408889634f, kbv));  // kbv: 0 or -inf (padding key)
+          tp_[hf * 4 + r] = f2bf(p);
+          tds[hf * 4 + r] = f2bf(p * dpt[r]);
+        }
+      } else {
+        const f32x4 m4 = *(const f32x4*)(mrow + qt * 16 + fq * 4);
+        const f32x4 l4 = *(const f32x4*)(lrow + qt * 16 + fq * 4);
+        const f32x4 d4 = *(const f32x4*)(drow + qt * 16 + fq * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf((st[r] * alpha + kbv - m4[r]) - l4[r]);
+          tp_[hf * 4 + r] = f2bf(p);
+          tds[hf * 4 + r] = f2bf(keep ? p * (dpt[r] - d4[r]) * alpha : 0.f);
+        }
       }
     }
     const mfma16x8 pb = __builtin_bit_cast(mfma16x8, tp_), dsb = __builtin_bit_cast(mfma16x8, tds);
@@ -727,7 +756,7 @@ __device__ __forceinline__ void bwd_key_tile(const char* Qs, const char* dOs, co
   for (int dt = 0; dt < 6; ++dt) {
     const u16x4 xv = xraw[dt];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { x[dt][r] = bf2f(xv[r]); ss += x[dt][r] * x[dt][r]; }
+    for (int r = 0; r < 4; ++r) { x[dt][r] = bf2f(xv[r]); ss += x[dt][r] * x[dt][r]; if constexpr (FAST) dka[dt][r] *= alpha; }
   }
   ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
   const float rr = rsqrtf(ss / DH + 1e-6f);
@@ -812,8 +841,9 @@ __device__ __forceinline__ void flush_scale_grads(const AttnBwdArgs& g, float* s
 // problem: two waves per SIMD to overlap LDS/exp latency with the other's MFMAs, compute = max(a, b) instead of a + b.
 // X: cross attention -- a "problem" is (sequence, head, 128-key chunk): query-side rows (q, dO, O, lse: g.S per sequence) and key-side rows
 // (k, v: the chunk) come from different places, role (a) emits dq^ partials instead of dq (see bwd_query_tile).
-template <int KT, bool X = false>
+template <int KT, bool X = false, bool FAST = false>  // FAST: no key mask (g.km == nullptr), self attention -- see bwd_query_tile
 __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
+  static_assert(!(X && FAST), "the cross-attention form keeps the masked arithmetic");
   constexpr int S_pad = KT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem; char* Ks = Qs + img_bytes(S_pad); char* Vs = Ks + img_bytes(S_pad); char* dOs = Vs + img_bytes(S_pad);
@@ -848,16 +878,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
 #ifdef SPA3D_ABLATE
     if (!(g.ablate & 2)) {
 #endif
-    rows_load<NP, 128>(rq, g.q + row0 * g.ldq + h * DH, g.ldq, S);
-    rows_load<NP, 128>(rk, g.k + krow0 * g.ldk + h * DH, g.ldk, Sk);
-    rows_load<NP, 128>(rv, g.v + krow0 * g.ldv + h * DH, g.ldv, Sk);
-    rows_load<NP, 128>(rd, g.d_o + row0 * E + h * DH, E, S);
-    rows_load<NP, 128>(ro, g.o + row0 * E + h * DH, E, S);
+    const int tid_o = opaque_tid();  // per-problem copy: the row offsets below are recomputed, not hoisted out of the loop and spilled (rows_load)
+    rows_load<NP, 128>(rq, g.q + row0 * g.ldq + h * DH, g.ldq, S, tid_o);
+    rows_load<NP, 128>(rk, g.k + krow0 * g.ldk + h * DH, g.ldk, Sk, tid_o);
+    rows_load<NP, 128>(rv, g.v + krow0 * g.ldv + h * DH, g.ldv, Sk, tid_o);
+    rows_load<NP, 128>(rd, g.d_o + row0 * E + h * DH, E, S, tid_o);
+    rows_load<NP, 128>(ro, g.o + row0 * E + h * DH, E, S, tid_o);
     __syncthreads();  // previous problem's LDS reads are done
     rows_store<true, NP, 128>(rq, S_pad, sscale, Qs);
     rows_store<true, NP, 128>(rk, S_pad, sscale + DH, Ks);
     rows_store<false, NP, 128>(rv, S_pad, nullptr, Vs);
-    store_do_delta<NP, 128>(rd, ro, S_pad, dOs, drow);
+    store_do_delta<NP, 128, FAST>(rd, ro, S_pad, dOs, drow);  // FAST: -delta
 #ifdef SPA3D_ABLATE
     }
 #endif
@@ -866,7 +897,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
       if (t >= Sk) b = -__builtin_inff();
       else if (g.km && g.km[krow0 + t] == 0.f) b = NEG_BIG;
       if (t < S) { m = g.lse[(row0 * g.H + (int64_t)h * S + t) * 2]; ll = g.lse[(row0 * g.H + (int64_t)h * S + t) * 2 + 1]; }
-      kbias[t] = b; mrow[t] = m; lrow[t] = ll;
+      kbias[t] = b;
+      if constexpr (FAST) mrow[t] = -(m + ll) * 9.797958971132712f;  // -(m + l) / alpha (padding query: -inf -> P = 0)
+      else { mrow[t] = m; lrow[t] = ll; }
     }
     __syncthreads();
 #ifdef SPA3D_ABLATE
@@ -895,7 +928,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
 #else
         const int nrows_st = S - q0;
 #endif
-        bwd_query_tile<KT, X>(Ks, Vs, kbias, sscale, qb, dob, mrow[q0 + fr], lrow[q0 + fr], drow[q0 + fr], xraw, valid, wt,
+        bwd_query_tile<KT, X, FAST>(Ks, Vs, kbias, sscale, qb, dob, mrow[q0 + fr], lrow[q0 + fr], drow[q0 + fr], xraw, valid, wt,
                               g.dq + (row0 + q0) * g.ldq + h * DH, g.ldq, nrows_st, ds_acc,
                               X ? g.dqpart + ((pi * g.S) + q0) * DH : nullptr
 #ifdef SPA3D_ABLATE
@@ -924,8 +957,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
 #else
         const int nrows_st = Sk - k0;
 #endif
-        bwd_key_tile<KT>(Qs, dOs, mrow, lrow, drow, sscale + DH, kb, vb, kbias[k0 + fr], xraw, valid, wt, g.dk + (krow0 + k0) * g.ldk + h * DH,
-                         g.ldk, g.dv + (krow0 + k0) * g.ldv + h * DH, g.ldv, nrows_st, ds_acc);
+        bwd_key_tile<KT, FAST>(Qs, dOs, mrow, lrow, drow, sscale + DH, kb, vb, kbias[k0 + fr], xraw, valid, wt, g.dk + (krow0 + k0) * g.ldk + h * DH,
+                               g.ldk, g.dv + (krow0 + k0) * g.ldv + h * DH, g.ldv, nrows_st, ds_acc);
       }
     }
   }
@@ -958,8 +991,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
 #ifndef SPA3D_B1_PREFETCH   // 1: the next problem's q / k rows are requested at the start of phase 2 (software pipeline over problems)
 #define SPA3D_B1_PREFETCH 0
 #endif
-#ifndef SPA3D_B1_HOLD       // 1: a wave's last key tile's dk / dv rows are held across the phase barrier and leave through its wave tile
-#define SPA3D_B1_HOLD 0
+#ifndef SPA3D_B1_PIPE       // 1: hand-sequenced software pipeline of the key tile's query-tile pairs (no-mask 8-wave form)
+#define SPA3D_B1_PIPE 0
 #endif
 #ifndef SPA3D_B1_FLUSH      // scale-gradient partials: 0 per-phase DPP reduction + LDS atomics, 1 DPP reduction only (WRONG sums: timing experiment)
 #define SPA3D_B1_FLUSH 0
@@ -1061,10 +1094,11 @@ struct Bwd1Lds {  // row / column constants of the single-orientation kernel
 // `lane`: an OPAQUE copy of the lane index made by the caller per phase (opaque_tid): every lane-constant address below is then recomputed per
 // tile instead of being hoisted out of the problem loop, spilled, and reloaded behind s_waitcnt vmcnt(0) -- which would also wait for the next
 // problem's prefetched rows
-template <int KT, bool MASK>
+template <int KT, bool MASK, bool SPLIT_TR = false>  // SPLIT_TR: the dO^T and xq^T fragments of a query-tile pair are read one after the other (24 fewer live registers: the 12-wave form)
 __device__ __forceinline__ void bwd1_key_tile(int lane, const char* Qs, const char* dOs, const char* krow /* x^k image row of this lane's key */, char* dSrow,
                                               const Bwd1Lds& L, const mfma16x8 (&kb)[3], const mfma16x8 (&vb)[3], float kbv, float rrk, bool valid,
-                                              u16x4 (&kout)[6], u16x4 (&vout)[6], float (&ds_acc)[6][4]) {
+                                              bf16_t* gk_row, bf16_t* gv_row /* this lane's dk / dv row (d = 4fq), or nullptr past the end */,
+                                              float (&ds_acc)[6][4]) {
   const int fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
   const float alpha = 0.10206207261596575f, c2 = 0.10206207261596575f * 1.4426950408889634f;  // 1/sqrt(96), times log2(e)
   const bool keep = kbv == 0.f;
@@ -1072,6 +1106,84 @@ __device__ __forceinline__ void bwd1_key_tile(int lane, const char* Qs, const ch
   f32x4 dva[6], dka[6];
 #pragma unroll
   for (int dt = 0; dt < 6; ++dt) { dva[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dka[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#if SPA3D_B1_PIPE
+  if constexpr (!MASK && !SPLIT_TR) {
+    // Software pipeline over query-tile pairs, LDS reads sequenced by hand: while pair s2's transposed fragments (group T, 24 reads) are in
+    // flight (T1: dO^T, T2: xq^T), the scores of pair s2+1 are computed from fragment reads issued before T1 (group A: first query tile) and behind
+    // T2 (group B: second); every group is retired by a counted wait <= 15 (lgkmcnt is a 4-bit counter; LDS operations return in order).
+    const char* qa = Qs + row_off(fr) + fq * 16;   // row-major fragment base of this lane (query-tile 0); tile qt: + qt * ROW16
+    const char* da = dOs + row_off(fr) + fq * 16;
+    const char* ma = (const char*)(L.mrow + fq * 4); const char* na = (const char*)(L.ndrow + fq * 4);  // + qt * 64
+    struct Half { uint4 st0, dp0, q[3], d[3]; };
+    auto issue_half = [&](Half& hh, int qt) {
+      const char* q_ = qa + qt * ROW16; const char* d_ = da + qt * ROW16;
+      hh.st0 = lds_b128_o<0>(ma + qt * 64); hh.dp0 = lds_b128_o<0>(na + qt * 64);
+      hh.q[0] = lds_b128_o<0>(q_); hh.q[1] = lds_b128_o<64>(q_); hh.q[2] = lds_b128_o<128>(q_);
+      hh.d[0] = lds_b128_o<0>(d_); hh.d[1] = lds_b128_o<64>(d_); hh.d[2] = lds_b128_o<128>(d_);
+    };
+    auto score_half = [&](const Half& hh, int hf, u16x8& tp_, u16x8& tds, char* dsp) {
+      f32x4 st = __builtin_bit_cast(f32x4, hh.st0), dpt = __builtin_bit_cast(f32x4, hh.dp0);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        st = MFMA16(__builtin_bit_cast(mfma16x8, hh.q[s]), kb[s], st);
+        dpt = MFMA16(__builtin_bit_cast(mfma16x8, hh.d[s]), vb[s], dpt);
+      }
+      u16x4 d4_;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[r], c2, kb2));
+        tp_[hf * 4 + r] = f2bf(p);
+        d4_[r] = f2bf(p * dpt[r]);
+        tds[hf * 4 + r] = d4_[r];
+      }
+      *(u16x4*)dsp = d4_;
+    };
+    u16x8 tpc, tdc;
+    {
+      Half h0, h1;
+      issue_half(h0, 0); issue_half(h1, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      score_half(h0, 0, tpc, tdc, dSrow + fq * 8);
+      score_half(h1, 1, tpc, tdc, dSrow + 32 + fq * 8);
+    }
+#pragma unroll 1
+    for (int s2 = 0; s2 < KT / 2; ++s2) {
+      const mfma16x8 pb = __builtin_bit_cast(mfma16x8, tpc), dsb = __builtin_bit_cast(mfma16x8, tdc);
+      const bool more = s2 + 1 < KT / 2;
+      const int qn = more ? 2 * s2 + 2 : 0;  // (last trip: harmless re-read of pair 0, results unused)
+      Half ha, hb;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the dS store of the previous scores is out of the counter
+      issue_half(ha, qn);                                                     // group A: 8 reads
+      const int roff = 2 * s2 * ROW16 + row_off(4 * fq + tq) + tp * 8;
+      const char* ob = dOs + roff; const char* qb_ = Qs + roff;
+      uint2 olo[6], ohi[6];                                                   // group T1: 12 transposed reads (dO^T)
+      static_for<0, 6>([&](auto dtc) { constexpr int dt = decltype(dtc)::value; olo[dt] = lds_tr16_b64_o<dt * 32>(ob); ohi[dt] = lds_tr16_b64_o<ROW16 + dt * 32>(ob); });
+      u16x8 tpn, tdn;
+      asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");                     // A landed (lgkmcnt is a 4-bit counter: groups are sized to waits <= 15)
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) score_half(ha, 0, tpn, tdn, dSrow + (qn * 16 + fq * 4) * 2);
+      __builtin_amdgcn_sched_barrier(0);
+      uint2 qlo[6], qhi[6];                                                   // group T2: 12 transposed reads (xq^T)
+      static_for<0, 6>([&](auto dtc) { constexpr int dt = decltype(dtc)::value; qlo[dt] = lds_tr16_b64_o<dt * 32>(qb_); qhi[dt] = lds_tr16_b64_o<ROW16 + dt * 32>(qb_); });
+      asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");                     // T1 (and the dS store) landed
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < 6; ++dt) dva[dt] = MFMA16(__builtin_bit_cast(mfma16x8, make_uint4(olo[dt].x, olo[dt].y, ohi[dt].x, ohi[dt].y)), pb, dva[dt]);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_half(hb, qn + 1);                                                 // group B: 8 reads
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                      // T2 landed
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < 6; ++dt) dka[dt] = MFMA16(__builtin_bit_cast(mfma16x8, make_uint4(qlo[dt].x, qlo[dt].y, qhi[dt].x, qhi[dt].y)), dsb, dka[dt]);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) score_half(hb, 1, tpn, tdn, dSrow + ((qn + 1) * 16 + fq * 4) * 2);
+      tpc = tpn; tdc = tdn;
+    }
+  } else
+#endif
 #pragma unroll 1
   for (int s2 = 0; s2 < KT / 2; ++s2) {
     u16x8 tp_, tds;
@@ -1112,36 +1224,54 @@ __device__ __forceinline__ void bwd1_key_tile(int lane, const char* Qs, const ch
     }
     const mfma16x8 pb = __builtin_bit_cast(mfma16x8, tp_), dsb = __builtin_bit_cast(mfma16x8, tds);
     // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Xq^T[d][q] dS[q][key]
-    uint2 olo[6], ohi[6], qlo[6], qhi[6];
     const int roff = 2 * s2 * ROW16 + row_off(4 * fq + tq) + tp * 8;
     const char* ob = dOs + roff; const char* qb_ = Qs + roff;
-    static_for<0, 6>([&](auto dtc) {
-      constexpr int dt = decltype(dtc)::value;
-      olo[dt] = lds_tr16_b64_o<dt * 32>(ob); ohi[dt] = lds_tr16_b64_o<ROW16 + dt * 32>(ob);
-      qlo[dt] = lds_tr16_b64_o<dt * 32>(qb_); qhi[dt] = lds_tr16_b64_o<ROW16 + dt * 32>(qb_);
-    });
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SPLIT_TR) {
+      uint2 lo[6], hi[6];
+      static_for<0, 6>([&](auto dtc) { constexpr int dt = decltype(dtc)::value; lo[dt] = lds_tr16_b64_o<dt * 32>(ob); hi[dt] = lds_tr16_b64_o<ROW16 + dt * 32>(ob); });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int dt = 0; dt < 6; ++dt) {
-      const uint4 uo = make_uint4(olo[dt].x, olo[dt].y, ohi[dt].x, ohi[dt].y);
-      const uint4 uq = make_uint4(qlo[dt].x, qlo[dt].y, qhi[dt].x, qhi[dt].y);
-      dva[dt] = MFMA16(__builtin_bit_cast(mfma16x8, uo), pb, dva[dt]);
-      dka[dt] = MFMA16(__builtin_bit_cast(mfma16x8, uq), dsb, dka[dt]);
+      for (int dt = 0; dt < 6; ++dt) dva[dt] = MFMA16(__builtin_bit_cast(mfma16x8, make_uint4(lo[dt].x, lo[dt].y, hi[dt].x, hi[dt].y)), pb, dva[dt]);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, 6>([&](auto dtc) { constexpr int dt = decltype(dtc)::value; lo[dt] = lds_tr16_b64_o<dt * 32>(qb_); hi[dt] = lds_tr16_b64_o<ROW16 + dt * 32>(qb_); });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < 6; ++dt) dka[dt] = MFMA16(__builtin_bit_cast(mfma16x8, make_uint4(lo[dt].x, lo[dt].y, hi[dt].x, hi[dt].y)), dsb, dka[dt]);
+    } else {
+      uint2 olo[6], ohi[6], qlo[6], qhi[6];
+      static_for<0, 6>([&](auto dtc) {
+        constexpr int dt = decltype(dtc)::value;
+        olo[dt] = lds_tr16_b64_o<dt * 32>(ob); ohi[dt] = lds_tr16_b64_o<ROW16 + dt * 32>(ob);
+        qlo[dt] = lds_tr16_b64_o<dt * 32>(qb_); qhi[dt] = lds_tr16_b64_o<ROW16 + dt * 32>(qb_);
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < 6; ++dt) {
+        const uint4 uo = make_uint4(olo[dt].x, olo[dt].y, ohi[dt].x, ohi[dt].y);
+        const uint4 uq = make_uint4(qlo[dt].x, qlo[dt].y, qhi[dt].x, qhi[dt].y);
+        dva[dt] = MFMA16(__builtin_bit_cast(mfma16x8, uo), pb, dva[dt]);
+        dka[dt] = MFMA16(__builtin_bit_cast(mfma16x8, uq), dsb, dka[dt]);
+      }
     }
   }
   // lane: key = k0 + fr, d = 16dt + 4fq + r.  dV rows are packed first (their registers die), then dK^ = alpha g_q o dka and the RMSNorm backward of k
 #pragma unroll
-  for (int dt = 0; dt < 6; ++dt)
+  for (int dt = 0; dt < 6; ++dt) {
+    u16x4 v4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) vout[dt][r] = f2bf(dva[dt][r]);
+    for (int r = 0; r < 4; ++r) v4[r] = f2bf(dva[dt][r]);
+    if (gv_row) *(u16x4*)(gv_row + dt * 16) = v4;  // 8-byte row pieces straight from the accumulator layout
+  }
 #pragma unroll
   for (int dt = 0; dt < 6; ++dt) {
     const f32x4 a4 = *(const f32x4*)(L.agq + dt * 16 + fq * 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) dka[dt][r] *= a4[r];
   }
-  rms_bwd_tile(lane, dka, krow, rrk, L.gk, valid, ds_acc, [&](int dt, u16x4 k4) { kout[dt] = k4; });
+  rms_bwd_tile(lane, dka, krow, rrk, L.gk, valid, ds_acc, [&](int dt, u16x4 k4) { if (gk_row) *(u16x4*)(gk_row + dt * 16) = k4; });
 }
 
 // phase 2: one 16-query tile.  dQ^[q][d] = alpha g_k[d] sum_keys xk[key][d] dS[q][key]; then the RMSNorm backward of q (lane: query fr, d = 16dt+4fq+r)
@@ -1189,12 +1319,21 @@ __device__ __forceinline__ void bwd1_query_tile(int lane, const char* Ks, const 
 #pragma unroll
     for (int r = 0; r < 4; ++r) dqa[dt][r] *= a4[r];
   }
-  rms_bwd_tile(lane, dqa, qrow, rrq, L.gq, valid, ds_acc, [&](int dt, u16x4 o4) { tile_put(wt, dt, o4, lane); });
-  tile_flush(wt, gtile, ld_, nrows, lane);
+  if (wt) {  // wave-uniform
+    rms_bwd_tile(lane, dqa, qrow, rrq, L.gq, valid, ds_acc, [&](int dt, u16x4 o4) { tile_put(wt, dt, o4, lane); });
+    tile_flush(wt, gtile, ld_, nrows, lane);
+  } else {
+    rms_bwd_tile(lane, dqa, qrow, rrq, L.gq, valid, ds_acc, [&](int dt, u16x4 o4) {
+      if (fr < nrows) *(u16x4*)(gtile + (int64_t)fr * ld_ + dt * 16 + fq * 4) = o4;
+    });
+  }
 }
 
-template <int KT, bool MASK>
-__global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnBwdArgs g) {
+// NW waves per workgroup: 8 (two per SIMD, 256 registers) or 12 (three per SIMD, 168 registers: every key / query tile of S <= 160 in ONE round, and a
+// third dependency chain per SIMD to hide the LDS / MFMA latencies the phases are bound by)
+template <int KT, bool MASK, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd1_kernel(AttnBwdArgs g) {
+  constexpr int NTH = NW * 64, RPP = NW * 16;
   constexpr int S_pad = KT * 16, IMG = img_bytes(S_pad);
   static_assert(S_pad * 2 + 32 <= DSROW, "dS image row");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1204,15 +1343,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnBwdArgs g) {
   L.rk = L.rq + S_pad; L.sred = L.rk + S_pad; L.gq = L.sred + 2 * DH; L.gk = L.gq + DH; L.gqk = L.gk + DH; L.agq = L.gqk + DH; L.agk = L.agq + DH;
   const int E = g.H * DH;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, fr = lane & 15, fq = lane >> 4;
-  char* wt = dOs + wv * WTILE;  // phase-2 output tile of this wave: the dO image is dead by then
-  for (int t = tid; t < DH; t += 512) {
+  
+  for (int t = tid; t < DH; t += NTH) {
     const float a = g.sq[t], b = g.sk[t];
     L.gq[t] = a; L.gk[t] = b; L.gqk[t] = a * b; L.agq[t] = 0.10206207261596575f * a; L.agk[t] = 0.10206207261596575f * b;
     L.sred[t] = 0.f; L.sred[DH + t] = 0.f;
   }
   __syncthreads();
   const int64_t nseq = g.nprob / g.H;
-  constexpr int NP = (S_pad + 127) / 128;
+  constexpr int NP = (S_pad + RPP - 1) / RPP;
   constexpr int abl = SPA3D_ABL1;  // diagnostic builds only (tools/ablate_attn.py compiles one object per mask); 0 in the product: everything below folds away
   // Software pipeline over this workgroup's problems: the NEXT problem's q, k, dO, O rows are requested at the start of phase 2 and land in
   // registers under it (phase 2 needs few), so the top of the loop finds them there instead of paying a memory latency per problem.
@@ -1229,11 +1368,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnBwdArgs g) {
   auto request_qk = [&](int64_t row0_, int S_, int h_) {
     if constexpr (!(abl & 2)) {
       const int t_ = opaque_tid();
-      rows_load<NP, 128>(rq, g.q + row0_ * g.ldq + h_ * DH, g.ldq, S_, t_);
-      rows_load<NP, 128>(rk, g.k + row0_ * g.ldk + h_ * DH, g.ldk, S_, t_);
+      rows_load<NP, RPP>(rq, g.q + row0_ * g.ldq + h_ * DH, g.ldq, S_, t_);
+      rows_load<NP, RPP>(rk, g.k + row0_ * g.ldk + h_ * DH, g.ldk, S_, t_);
     }
   };
-  constexpr bool PREFETCH = SPA3D_B1_PREFETCH != 0, HOLD = SPA3D_B1_HOLD != 0;
+  constexpr bool PREFETCH = SPA3D_B1_PREFETCH != 0;
   int64_t pi = blockIdx.x;
   if (pi < g.nprob) { params(pi, row0, S, h); if (PREFETCH) request_qk(row0, S, h); }
   while (pi < g.nprob) {
@@ -1241,15 +1380,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnBwdArgs g) {
     const int tid_o = opaque_tid();
     if (!PREFETCH) request_qk(row0, S, h);
     if constexpr (!(abl & 2)) {
-      rows_load<NP, 128>(rd, g.d_o + row0 * E + h * DH, E, S, tid_o);
-      rows_load<NP, 128>(ro, g.o + row0 * E + h * DH, E, S, tid_o);
+      rows_load<NP, RPP>(rd, g.d_o + row0 * E + h * DH, E, S, tid_o);
+      rows_load<NP, RPP>(ro, g.o + row0 * E + h * DH, E, S, tid_o);
     }
     __syncthreads();  // previous problem's phase-2 reads (Xq, Xk, dS) and tile traffic (dO region) are done
     if constexpr (!(abl & 2)) {
-      rows_store_xhat<NP, 128>(rq, S_pad, Qs, L.rq, tid_o);
-      rows_store_xhat<NP, 128>(rk, S_pad, Ks, L.rk, tid_o);
+      rows_store_xhat<NP, RPP>(rq, S_pad, Qs, L.rq, tid_o);
+      rows_store_xhat<NP, RPP>(rk, S_pad, Ks, L.rk, tid_o);
     }
-    for (int t = tid_o; t < S_pad; t += 512) {
+    for (int t = tid_o; t < S_pad; t += NTH) {
       float b = 0.f, m = 0.f, ll = __builtin_inff();  // padding query: P = exp(.. - inf) = 0
       if (t >= S) b = -__builtin_inff();
       else if (MASK && g.km[row0 + t] == 0.f) b = NEG_BIG;
@@ -1268,45 +1407,34 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnBwdArgs g) {
       for (int s = 0; s < 3; ++s) { kx[s] = *(const u16x8*)(kp + s * 32); vx[s] = *(const u16x8*)(vp + s * 32); }
     };
     if (wv < QT) load_own(wv);  // (L2-warm: the staging loads just fetched these rows)
-    if constexpr (!(abl & 2)) store_do_delta<NP, 128, true>(rd, ro, S_pad, dOs, L.ndrow, tid_o);  // -delta: the dP accumulators' initial value
+    if constexpr (!(abl & 2)) store_do_delta<NP, RPP, true>(rd, ro, S_pad, dOs, L.ndrow, tid_o);  // -delta: the dP accumulators' initial value
     __syncthreads();
     const int64_t pn = pi + gridDim.x;
     int64_t row0n = 0; int Sn = 0, hn = 0;
     // ---------------------------------------------------------------- phase 1: key tiles -> dk, dv, dS image
-    const int QT1 = (abl & 16) ? min(QT, 8) : QT;          // 16: first round of tiles only
-    u16x4 hk[6], hv[6]; int hold_k0 = -1;                  // the wave's LAST key tile's dk / dv rows, stored through its tile in phase 2
+    const int QT1 = (abl & 16) ? min(QT, NW) : QT;          // 16: first round of tiles only
     if constexpr (!(abl & 1)) {                            // 1: staging only
       float dsk_acc[6][4];
 #pragma unroll
       for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dsk_acc[i][r] = 0.f;
-      for (int kt = wv; kt < QT1; kt += 8) {
+      for (int kt = wv; kt < QT1; kt += (NW >= KT ? KT : NW)) {  // (NW >= KT: at most one trip, and the compiler can see it)
         const int k0 = kt * 16;
         const int lo_ = opaque_tid() & 63, fr = lo_ & 15, fq = lo_ >> 4;  // shadows the kernel-scope fr / fq: recomputed per tile, not hoisted
         mfma16x8 kb[3], vb[3];
         frag_norm(kx, L.gqk, fq, kb);  // 16-bit(x r g_k g_q): with xq in the image, S = alpha sum_d xq kb
 #pragma unroll
         for (int s = 0; s < 3; ++s) vb[s] = __builtin_bit_cast(mfma16x8, vx[s]);
-        if (kt + 8 < QT) load_own(kt + 8);  // the second tile's rows arrive under the first tile's MFMAs
-        u16x4 ko[6], vo[6];
-        bwd1_key_tile<KT, MASK>(lo_, Qs, dOs, Ks + row_off(k0 + fr), dSs + (k0 + fr) * DSROW, L, kb, vb, L.kbias[k0 + fr], L.rk[k0 + fr], k0 + fr < S, ko, vo,
-                                dsk_acc);
-        if (!HOLD || kt + 8 < QT1) {  // (HOLD: not the wave's last tile) 8-byte row pieces straight from the accumulator layout
-          if (!(abl & 128) && k0 + fr < S) {
-            bf16_t* gk_ = g.dk + (row0 + k0 + fr) * g.ldk + h * DH + fq * 4; bf16_t* gv_ = g.dv + (row0 + k0 + fr) * g.ldv + h * DH + fq * 4;
-#pragma unroll
-            for (int dt = 0; dt < 6; ++dt) { *(u16x4*)(gk_ + dt * 16) = ko[dt]; *(u16x4*)(gv_ + dt * 16) = vo[dt]; }
-          }
-        } else {
-#pragma unroll
-          for (int dt = 0; dt < 6; ++dt) { hk[dt] = ko[dt]; hv[dt] = vo[dt]; }
-          hold_k0 = k0;
-        }
+        if (kt + NW < QT) load_own(kt + NW);  // the second tile's rows arrive under the first tile's MFMAs
+        const bool st_ = !(abl & 128) && k0 + fr < S;     // 128: no dk / dv stores
+        bwd1_key_tile<KT, MASK, (NW > 8)>(lo_, Qs, dOs, Ks + row_off(k0 + fr), dSs + (k0 + fr) * DSROW, L, kb, vb, L.kbias[k0 + fr], L.rk[k0 + fr], k0 + fr < S,
+                                          st_ ? g.dk + (row0 + k0 + fr) * g.ldk + h * DH + fq * 4 : nullptr,
+                                          st_ ? g.dv + (row0 + k0 + fr) * g.ldv + h * DH + fq * 4 : nullptr, dsk_acc);
       }
       if constexpr (!(abl & 256)) flush_ds_acc(dsk_acc, L.sred + DH);  // 256: no scale-gradient flushes
       // key tiles past the sequence end (ragged sequences): their dS rows must read as zeros in phase 2 (xk rows there are zero, but 0 x NaN = NaN)
-      for (int kt = QT + wv; kt < KT; kt += 8) {
+      for (int kt = QT + wv; kt < KT; kt += NW) {
         char* rowp = dSs + (kt * 16 + fr) * DSROW + fq * 8;
 #pragma unroll
         for (int qt = 0; qt < KT; ++qt) *(u16x4*)(rowp + qt * 32) = u16x4{0, 0, 0, 0};
@@ -1314,31 +1442,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd1_kernel(AttnBwdArgs g) {
     }
     __syncthreads();
     // ---------------------------------------------------------------- phase 2: query tiles -> dq (and the held dk / dv rows)
-    if constexpr (!(abl & 1) && !(abl & 32)) {             // 32: no phase 2
-      if (hold_k0 >= 0 && !(abl & 128)) {
-        const int lo_ = opaque_tid() & 63;
-        char* wt_ = dOs + (opaque_tid() >> 6) * WTILE;
-#pragma unroll
-        for (int dt = 0; dt < 6; ++dt) tile_put(wt_, dt, hk[dt], lo_);
-        tile_flush(wt_, g.dk + (row0 + hold_k0) * g.ldk + h * DH, g.ldk, S - hold_k0, lo_);
-#pragma unroll
-        for (int dt = 0; dt < 6; ++dt) tile_put(wt_, dt, hv[dt], lo_);
-        tile_flush(wt_, g.dv + (row0 + hold_k0) * g.ldv + h * DH, g.ldv, S - hold_k0, lo_);
-      }
-    }
     // next problem's rows: in flight under phase 2.  Unconditional (the last iteration re-requests its own rows, never used): a conditional
     // request makes the row registers loop-carried through phase 1 in the compiler's eyes (309 spilled VGPRs)
     params(pn < g.nprob ? pn : pi, row0n, Sn, hn); if (PREFETCH) request_qk(row0n, Sn, hn);
-    if constexpr (!(abl & 1) && !(abl & 32)) {
+    if constexpr (!(abl & 1) && !(abl & 32)) {             // 32: no phase 2
       float dsq_acc[6][4];
 #pragma unroll
       for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dsq_acc[i][r] = 0.f;
-      for (int qt = wv; qt < QT1; qt += 8) {
+      for (int qt = wv; qt < QT1; qt += (NW >= KT ? KT : NW)) {
         const int q0 = qt * 16;
         const int lo_ = opaque_tid() & 63, fr = lo_ & 15;
-        char* wt_ = dOs + (opaque_tid() >> 6) * WTILE;
+        const int wv_ = opaque_tid() >> 6;
+        char* wt_ = wv_ < 8 ? dOs + wv_ * WTILE : nullptr;  // eight tiles fit the dead dO image; further waves store 8-byte pieces directly
         bwd1_query_tile<KT>(lo_, Ks, dSs, Qs + row_off(q0 + fr), qt, L, L.rq[q0 + fr], q0 + fr < S, wt_, g.dq + (row0 + q0) * g.ldq + h * DH, g.ldq,
                             S - q0, dsq_acc);
       }
@@ -1511,21 +1628,30 @@ static void launch_bwd(spa3d_ctx* c, const AttnBwdArgs& a) {
     attr_set = true;
   }
   if constexpr (S_pad <= 160 && KT >= 2) {
-    if (mode == 4) {  // single-orientation kernel (round 3)
+    if (mode == 4 || mode == 5) {  // single-orientation kernel (round 3), 8 waves; 5: its 12-wave form where there are nine or ten tiles
       const int lds1 = bwd1_lds_bytes(KT);
       static bool attr1 = false;
       if (!attr1) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel<KT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
-        (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel<KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+        (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel<KT, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+        (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel<KT, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+        (void)hipFuncSetAttribute((const void*)attn_bwd1_kernel<KT, false, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
         attr1 = true;
       }
-      if (a.km) attn_bwd1_kernel<KT, true><<<(unsigned)std::min<int64_t>(a.nprob, 1024), 512, lds1, c->stream>>>(a);
-      else attn_bwd1_kernel<KT, false><<<(unsigned)std::min<int64_t>(a.nprob, 1024), 512, lds1, c->stream>>>(a);
+      const unsigned grid = (unsigned)std::min<int64_t>(a.nprob, 1024);
+      if (a.km) attn_bwd1_kernel<KT, true, 8><<<grid, 512, lds1, c->stream>>>(a);
+      else if (mode == 4 || KT < 9) attn_bwd1_kernel<KT, false, 8><<<grid, 512, lds1, c->stream>>>(a);
+      else attn_bwd1_kernel<KT, false, 12><<<grid, 768, lds1, c->stream>>>(a);  // mode 5: twelve waves take nine or ten tiles in one round (168 registers: spills, measured slower)
       return;
     }
   }
   if constexpr (S_pad <= 160) {
-    if (mode == 1) { attn_bwd8_kernel<KT><<<(unsigned)std::min<int64_t>(a.nprob, 1024), 512, lds4, c->stream>>>(a); return; }
+    if (mode == 1) {
+      static bool attrf = false;
+      if (!attrf) { (void)hipFuncSetAttribute((const void*)attn_bwd8_kernel<KT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4); attrf = true; }
+      if (a.km) attn_bwd8_kernel<KT><<<(unsigned)std::min<int64_t>(a.nprob, 1024), 512, lds4, c->stream>>>(a);
+      else attn_bwd8_kernel<KT, false, true><<<(unsigned)std::min<int64_t>(a.nprob, 1024), 512, lds4, c->stream>>>(a);  // no key mask: cheap score arithmetic
+      return;
+    }
     if (mode == 2) { attn_bwd_split_kernel<KT, 4><<<(unsigned)std::min<int64_t>(a.nprob, 2048), 256, lds2(4), c->stream>>>(a); return; }
   }
   attn_bwd_split_kernel<KT, 8><<<(unsigned)std::min<int64_t>(a.nprob, 1024), 512, lds2(8), c->stream>>>(a);

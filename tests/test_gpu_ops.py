@@ -300,13 +300,13 @@ def test_linear_bwd_tiled_8phase(lib, monkeypatch, M, N, K):
   test_linear_bwd_tiled(lib, M, N, K)
 
 
-@pytest.mark.parametrize('bwd_mode', ['1', '2', '3', '4'])
+@pytest.mark.parametrize('bwd_mode', ['1', '2', '3', '4', '5'])
 @pytest.mark.parametrize('nseq,S,H,masked', [(5, 25, 8, True), (3, 129, 8, False), (4, 151, 8, True), (2, 128, 8, False), (3, 40, 2, True),
                                              (17, 151, 8, True), (3, 301, 8, True), (2, 200, 8, False), (2, 320, 4, True), (9, 193, 2, True), (3, 176, 8, True), (2, 160, 4, False)])
 def test_attention_fused_fwd_bwd(lib, monkeypatch, nseq, S, H, masked, bwd_mode):
   """LDS-resident fused forward / backward (impl=2) vs the fp64 oracle; packed q|k|v rows as the QKV projection writes them.
-  bwd_mode: 1 = four resident images + concurrent roles (S <= 160), 2 / 3 = split-pass with 4 / 8 waves, 4 = single orientation + dS hand-off
-  through LDS (S <= 160; round 3); S > 160 (BASELINE cfg#5: S = 301) always takes the 8-wave split-pass kernel.  nseq = 17 / 9 exercise the XCD-major problem map's identity tail."""
+  bwd_mode: 1 = four resident images + concurrent roles (S <= 160), 2 / 3 = split-pass with 4 / 8 waves, 4 / 5 = single orientation + dS hand-off
+  through LDS with 8 / 12 waves (S <= 160; round 3, opt-in); S > 160 (BASELINE cfg#5: S = 301) always takes the 8-wave split-pass kernel.  nseq = 17 / 9 exercise the XCD-major problem map's identity tail."""
   if S > 160 and bwd_mode != '3':
     pytest.skip('S > 160 has one backward structure')
   monkeypatch.setenv('SPA3D_ATTN_BWD_MODE', bwd_mode)

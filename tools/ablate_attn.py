@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import importlib
 b = importlib.import_module('3dspa_code_amd.build')
 out = os.path.join(ROOT, 'tools', '_ablate'); os.makedirs(out, exist_ok=True)
-MODE4 = os.environ.get('SPA3D_ATTN_BWD_MODE') == '4'
+MODE4 = os.environ.get('SPA3D_ATTN_BWD_MODE') in ('4', '5')
 lib_path = os.path.join(out, 'libspa3d_ablate.so')
 if not os.environ.get('ABL1_CHILD'):
   b.build(verbose=False)
@@ -17,7 +17,7 @@ if not os.environ.get('ABL1_CHILD'):
     ao = os.path.join(out, 'attention_fused_ablate.o')
     subprocess.check_call([b._hipcc()] + b.FLAGS + ['-DSPA3D_ABLATE', '-c', os.path.join(b.CSRC, 'attention_fused.hip'), '-o', ao])
     subprocess.check_call([b._hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib_path] + objs + [ao])
-if os.environ.get('SPA3D_ATTN_BWD_MODE') == '4' and not os.environ.get('ABL1_CHILD'):
+if MODE4 and not os.environ.get('ABL1_CHILD'):
   from concurrent.futures import ThreadPoolExecutor
   masks = [(0, 'full'), (1, 'staging only'), (2, 'no staging'), (16, 'first round of tiles only (tiles 0-7)'), (32, 'no phase 2'), (128, 'no dk/dv stores'),
            (256, 'no scale-gradient flushes'), (2 + 32 + 128 + 256, 'phase 1 alone (no staging, stores, flushes, phase 2)'),
@@ -64,13 +64,13 @@ def timeit(fn, n=5):
   e1.record(); torch.cuda.synchronize()
   return e0.elapsed_time(e1) / n
 assert fwd() == 0
-if os.environ.get('SPA3D_ATTN_BWD_MODE') == '4':  # single-orientation kernel (round 3): ONE OBJECT PER MASK (-DSPA3D_ABL1=mask, a compile-time
+if MODE4:  # single-orientation kernel (round 3): ONE OBJECT PER MASK (-DSPA3D_ABL1=mask, a compile-time
   # constant), so the code that remains is compiled exactly as in the product; each variant runs in a child process
   if os.environ.get('ABL1_CHILD'):
     kmp = None if os.environ.get('NOMASK') else km.data_ptr()
     bwd = lambda: lib.spa3d_op_attention_bwd(qkv[..., :E].data_ptr(), qkv[..., E:2*E].data_ptr(), qkv[..., 2*E:].data_ptr(), 3*E, 3*E, 3*E, sq.data_ptr(), sk.data_ptr(), kmp, nseq, S, S, H, Dh, o.data_ptr(), lse.data_ptr(), d_o.data_ptr(), dqkv[..., :E].data_ptr(), dqkv[..., E:2*E].data_ptr(), dqkv[..., 2*E:].data_ptr(), dsq.data_ptr(), dsk.data_ptr(), 1, 2, ws.data_ptr(), ws.numel(), s())
     assert lib.spa3d_op_attention(qkv[..., :E].data_ptr(), qkv[..., E:2*E].data_ptr(), qkv[..., 2*E:].data_ptr(), 3*E, 3*E, 3*E, sq.data_ptr(), sk.data_ptr(), kmp, nseq, S, S, H, Dh, o.data_ptr(), lse.data_ptr(), 1, 2, ws.data_ptr(), ws.numel(), s()) == 0
-    print(f'S={S} nseq={nseq} mode 4 {"nomask" if kmp is None else "mask"} ablate={os.environ["ABL1_CHILD"]}: bwd {timeit(bwd):.3f} ms', flush=True)
+    print(f'S={S} nseq={nseq} mode {os.environ["SPA3D_ATTN_BWD_MODE"]} {"nomask" if kmp is None else "mask"} ablate={os.environ["ABL1_CHILD"]}: bwd {timeit(bwd):.3f} ms', flush=True)
   sys.exit(0)
 for mask, what in ((0, 'full'), (1, 'staging only (no tile work)'), (2, 'tile work only (no staging)'), (4, 'no dq/dk/dv stores'), (6, 'tile work, no staging, no stores'),
                    (8, 'dQ role without its own S / dP (dS read from LDS): upper bound of a shared-dS structure'), (14, 'the same, tile work only')):
