@@ -148,6 +148,8 @@ struct spa3d_ctx {
   int prune = 1;          // drop masked frame tokens from the track encoder (3DSPA model, fused 16-bit attention path); SPA3D_PRUNE=0 disables
   float loss_scale = 1.f;  // the 16-bit backward runs at loss x scale, parameter gradients are scaled back at the end: 1 = off (bf16 / fp32),
                            // > 0 a fixed scale, < 0 automatic with |loss_scale| the target head-gradient magnitude (fp16 mode: -16)
+  void* grad_ev[2] = {nullptr, nullptr};  // spa3d_set_grad_events: recorded on the launch stream when a gradient segment is final (last chunk)
+  bool last_chunk = false;
   const float* loss_scale_state = nullptr;  // caller-owned device float (spa3d_set_loss_scale_state): dynamic multiplier of the loss scale
   double plan_stats[4] = {0, 0, 0, 0};  // last train call: encoder rows kept, encoder rows dense, readout slots, queries (spa3d_plan_stats)
   int attn_bwd_mode = 0;  // fused attention backward structure: 0 auto, 1 four images + concurrent roles, 2 split-pass 4 waves (2 WG/CU), 3 split-pass 8 waves

@@ -560,6 +560,15 @@ template <typename T> struct Net {
   }
 
 
+  // Overlap of the data-parallel gradient all-reduce with the backward: parameter gradients accumulate over the sample chunks, so
+  // a leaf is final only in the LAST chunk's backward -- in reverse graph order.  The caller may register two events (spa3d_set_grad_events);
+  // each is recorded on the launch stream when its segment of the flat gradient buffer (spa3d_grad_segments) has received its last
+  // contribution; the third segment (embedding, track encoder, state_init leaves) is final when the call's work is.  Not with a loss scale
+  // (fp16: the whole buffer is rescaled at the end).
+  void grad_segment_done(int i) {
+    if (c->dry || !c->last_chunk || !c->grad_ev[i] || c->loss_scale != 1.f) return;
+    if (hipEventRecord((hipEvent_t)c->grad_ev[i], c->stream) != hipSuccess && !c->hip_err) { c->hip_err = -6; c->err = "recording a gradient-segment event failed"; }
+  }
   // full backward of one chunk; parameter gradients accumulate into G
   void backward_chunk(Chunk& k, const spa3d_batch* b, int64_t b0, const float* denom_dev) {
     const int L = g.num_latent_tokens, Ld = g.latent_token_dim, dd = g.decoder_num_channels, Cl = dd - 128, To = g.num_output_frames;
@@ -588,6 +597,7 @@ template <typename T> struct Net {
       lin_bwd_w(qenc, k.sin2, dqtok, nq);
       c->ar.release(mk);
     }
+    grad_segment_done(0);  // track_readout_attn, query_encoder, track_predictor: final once the LAST chunk has come this far
     // ---- decompress_attn, decompressor, straight-through clip, compressor
     T* ddec = alloc<T>(nl * Cl);
     {
@@ -613,6 +623,7 @@ template <typename T> struct Net {
     k_zero(c, denc_out, nseq * d * (int64_t)sizeof(T));
     for (int i = (int)t2l.blocks.size() - 1; i >= 0; --i)
       block_bwd(t2l.blocks[i], k.t2l_st[i], dt2l, dt2l, k.Bc, L, nullptr, k.enc_out, k.N, denc_out);
+    grad_segment_done(1);  // tracks_to_latents, compressor, decompressor, decompress_attn
     k_bcast_grad<T>(c, dt2l, (int64_t)L * dl, k.Bc, (int64_t)L * dl, g_lat0);
     // ---- track encoder
     const int S = k.S;
@@ -683,6 +694,7 @@ void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
   }
   for (int64_t b0 = 0; b0 < b->B; b0 += Bc) {
     typename Net<T>::Chunk k{};
+    c->last_chunk = b0 + Bc >= b->B;
     k.Bc = std::min<int64_t>(Bc, b->B - b0); k.N = b->N; k.Q = b->Q; k.T_ = b->T; k.S = b->T + (g.model_kind == 1 ? 0 : 1); k.nseq = k.Bc * b->N;
     const int64_t mk = c->ar.mark();
     const float* lat = nullptr;
@@ -954,6 +966,22 @@ int spa3d_set_option(spa3d_handle h, const char* name, double value) {
 int spa3d_set_loss_scale_state(spa3d_handle h, const float* state) {
   if (!h) return SPA3D_ERR_ARG;
   h->loss_scale_state = state;
+  return SPA3D_OK;
+}
+int spa3d_grad_segments(spa3d_handle h, int64_t* bounds4) {
+  if (!h || !bounds4) return SPA3D_ERR_ARG;
+  int64_t b1 = -1, b2 = -1;
+  for (auto& l : h->leaves) {
+    if (b1 < 0 && l.name.rfind("tracks_to_latents/", 0) == 0) b1 = l.offset;
+    if (b2 < 0 && l.name.rfind("track_readout_attn/", 0) == 0) b2 = l.offset;
+  }
+  if (b1 < 0 || b2 < b1) return SPA3D_ERR_ARG;
+  bounds4[0] = 0; bounds4[1] = b1; bounds4[2] = b2; bounds4[3] = h->nparams;
+  return SPA3D_OK;
+}
+int spa3d_set_grad_events(spa3d_handle h, void* ev_readout, void* ev_latents) {
+  if (!h) return SPA3D_ERR_ARG;
+  h->grad_ev[0] = ev_readout; h->grad_ev[1] = ev_latents;
   return SPA3D_OK;
 }
 int spa3d_plan_stats(spa3d_handle h, double* out4) {

@@ -63,6 +63,29 @@ def allreduce_flat_(flat: torch.Tensor, bucket_elems: int, group=None, extra=(),
     w.wait()
 
 
+def allreduce_segments_overlapped_(flat: torch.Tensor, bounds, events, side: 'torch.cuda.Stream', bucket_elems: int, group=None, extra=()):
+  """SUM all-reduce of the flat gradient buffer in the order its segments become final during the last sample chunk's backward
+  (include/spa3d.h, spa3d_grad_segments): segment [b2, n) once `events[0]` has fired, [b1, b2) once `events[1]` has, both on the side stream
+  `side` and therefore UNDER the rest of the backward that is still running on the launch stream; [0, b1) and the `extra` scalars on the
+  launch stream behind everything.  The events were recorded by spa3d_loss_and_grads on the launch stream before it returned (the call
+  enqueues; it does not wait), so waiting for them here is well ordered.  Returns when every reduction has been enqueued and the launch
+  stream has been made to wait for the side stream."""
+  main = torch.cuda.current_stream(flat.device)
+  works = []
+  for ev, (lo, hi) in zip(events, ((bounds[2], bounds[3]), (bounds[1], bounds[2]))):
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+      for s_ in range(lo, hi, bucket_elems):
+        works.append(dist.all_reduce(flat[s_:min(s_ + bucket_elems, hi)], op=dist.ReduceOp.SUM, group=group, async_op=True))
+  for s_ in range(0, bounds[1], bucket_elems):
+    works.append(dist.all_reduce(flat[s_:min(s_ + bucket_elems, bounds[1])], op=dist.ReduceOp.SUM, group=group, async_op=True))
+  for t in extra:
+    works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True))
+  for w in works:
+    w.wait()  # stream-level wait (NCCL): the launch stream continues behind the reductions
+  main.wait_stream(side)
+
+
 def broadcast_state_(tensors, src: int = 0, group=None, force=False):
   """Replicas must start from rank `src`'s parameters and Adam moments whatever each rank initialised or loaded
   (a checkpoint read on rank 0 only, different seeds): one broadcast per buffer at construction / resume."""
@@ -95,7 +118,7 @@ class TrainState:
                total_steps: int = 1000000, weight_decay: float = 0.01, clip_norm: float = 1.0, b1: float = 0.9,
                b2: float = 0.999, eps: float = 1e-8, process_group: Optional[dist.ProcessGroup] = None,
                grad_bucket_bytes: int = 128 << 20, compute=None, adamw=None, noise_fn=None, force_collectives: bool = False,
-               evaluate=None):
+               evaluate=None, overlap_allreduce: bool = True):
     self.model = model
     self.params = params if hasattr(params, 'flat') and params.flat is not None else None
     flat = model.flat_from_tree(params)
@@ -121,6 +144,18 @@ class TrainState:
     self._noise_fn = noise_fn or _hip_uniform_noise
     self._evaluate = evaluate or self._hip_evaluate
     self._noise_cache = {}
+    # gradient all-reduce under the backward: needs the HIP compute (it records the segment events), a GPU, no loss scale
+    self._overlap = None
+    if overlap_allreduce and compute is None and on and flat.is_cuda and model.precision != 'fp16' and (self.world > 1 or self.force):
+      lib = _lib.load()
+      h = model._handle(*model._dims_from_params(self.params))[0]
+      b4 = (C.c_int64 * 4)()
+      _lib.check(lib.spa3d_grad_segments(h, b4), h, 'spa3d_grad_segments')
+      evs = (torch.cuda.Event(), torch.cuda.Event())
+      for e in evs:
+        e.record()  # instantiates the underlying hipEvent_t
+      _lib.check(lib.spa3d_set_grad_events(h, C.c_void_p(evs[0].cuda_event), C.c_void_p(evs[1].cuda_event)), h, 'spa3d_set_grad_events')
+      self._overlap = (tuple(int(x) for x in b4), evs, torch.cuda.Stream(device=flat.device))
     if model.precision == 'fp16' and compute is None and adamw is None:
       # dynamic loss scale: spa3d_adamw_step skips a step whose gradient norm is inf/NaN and halves the multiplier kept in scratch[4],
       # which the next spa3d_loss_and_grads on this handle applies (include/spa3d.h)
@@ -173,7 +208,11 @@ class TrainState:
     l3 = torch.stack([torch.as_tensor(ld[k], dtype=torch.float32, device=self.flat.device).reshape(())
                       for k in ('total_loss', 'position_loss', 'visible_loss')])
     # the per-rank gradients and loss terms already carry the global 1/denominator -> plain SUM over ranks
-    allreduce_flat_(self.grads, self.bucket_elems, self.pg, extra=(l3,), force=self.force)
+    if self._overlap is not None and multi:
+      bounds, evs, side = self._overlap
+      allreduce_segments_overlapped_(self.grads, bounds, evs, side, self.bucket_elems, self.pg, extra=(l3,))
+    else:
+      allreduce_flat_(self.grads, self.bucket_elems, self.pg, extra=(l3,), force=self.force)
     lr = self.schedule(self.step)
     self._adamw(self.flat, self.grads, self.m, self.v, lr, self.step, self.clip, self.b1, self.b2, self.eps, self.wd, self.scratch)
     self.step += 1

@@ -157,6 +157,18 @@ int spa3d_set_option(spa3d_handle h, const char* name, double value);
  * after 200 finite steps. */
 int spa3d_set_loss_scale_state(spa3d_handle h, const float* state);
 
+/* Overlapping the data-parallel gradient all-reduce with the backward (no reference counterpart: the reference is single-device, SURVEY 2;
+ * the split is SURVEY 8(e)'s).  Parameter gradients accumulate over the call's sample chunks, so a leaf is final only in the LAST chunk's
+ * backward, in reverse graph order.  spa3d_grad_segments: bounds4 = {0, b1, b2, n} (floats) cut the flat gradient buffer into
+ *   [b2, n)  track_readout_attn, query_encoder, track_predictor            -- final first  (event ev_readout)
+ *   [b1, b2) tracks_to_latents, compressor, decompressor, decompress_attn  -- final second (event ev_latents)
+ *   [0, b1)  state_init leaves, token / dino / depth projections, input_track_transformer -- final when the call's work is.
+ * spa3d_set_grad_events registers two hipEvent_t (or NULL to detach) that spa3d_loss_and_grads records on its stream at those two points of
+ * the last chunk; a collective on a side stream that waits for an event may then run under the rest of the backward.  Nothing is recorded
+ * on SPA3D_F16 handles (the loss-scaled buffer is rescaled as a whole at the end): use stream order there. */
+int spa3d_grad_segments(spa3d_handle h, int64_t* bounds4);
+int spa3d_set_grad_events(spa3d_handle h, void* ev_readout, void* ev_latents);
+
 /* Data-dependent plan sizes of the last spa3d_loss_and_grads / forward call on this handle, summed over its sample chunks:
  * out4 = {track-encoder token rows kept, token rows before pruning, distinct (sample, query frame) slots, queries}; zeros when the
  * respective saving is off.  Host values (they are the counts the call read back to size its launches). */

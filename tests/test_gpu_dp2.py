@@ -1,0 +1,77 @@
+"""Data parallelism with the REAL HIP step at world size 2 on the one GPU of the test box: two processes share cuda:0, the collectives go over
+gloo (RCCL refuses two ranks on one device; the collective library is not what is under test here -- TrainState's data-parallel logic around
+the library's own forward / backward / AdamW is: rank-0 broadcast, the global loss denominator, the rank slice of the global
+discretisation noise, the bucketed gradient SUM, clip + AdamW on reduced gradients).  Two steps on a 2-sample batch split 1 + 1 must equal
+the single-process steps on the whole batch (fp32 parity mode: only the summation order differs).  tests/test_dp_gloo.py covers the same
+logic on CPU with the oracle injected; tests/test_gpu_rccl.py runs RCCL itself at world size 1; bench.py --gpus N is the N-GPU run.
+BASELINE.json configs[3] (no reference counterpart: SURVEY 2)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = textwrap.dedent('''
+  import os, sys
+  sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+  import torch, torch.distributed as dist
+  from util import MINI, O, product_model
+  import spa3d
+  rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+  torch.cuda.set_device(0)
+  if world > 1:
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+  cfg = O.Config(**MINI, use_dino=True, use_depth=True, dino_feature_dim=24, depth_feature_dim=1)
+  full = {k: v.cuda() for k, v in O.synthetic_batch(2, 10, 6, 8, seed=5, dino_dim=24, depth_dim=1).items()}
+  full['query_tracks_visible'][0, :3] = 0   # unequal visible counts per shard: local denominators would be wrong
+  batch = {k: v[rank:rank + 1].contiguous() for k, v in full.items()} if world > 1 else full
+  model = product_model(spa3d, cfg, 'fp32')
+  # deliberately different initial parameters per rank: the construction-time broadcast must make them rank 0's
+  st = spa3d.TrainState(model, model.init(rank, full)['params'], learning_rate=1e-2, warmup_steps=1, total_steps=10, grad_bucket_bytes=4096)
+  losses = []
+  for _ in range(2):
+    m = st.train_step(batch)
+    losses.append(float(m['train/loss']))
+  torch.cuda.synchronize()
+  if rank == 0:
+    torch.save({'flat': st.flat.cpu(), 'losses': losses, 'gn': float(m['train/grad_norm'])}, os.environ['OUT'])
+  if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+''') % (ROOT, ROOT)
+
+
+def _launch(world, out, port):
+  procs = []
+  for r in range(world):
+    env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OUT=out)
+    procs.append(subprocess.Popen([sys.executable, '-c', CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+  outs = []
+  for p in procs:
+    try:
+      o, _ = p.communicate(timeout=600)
+    except subprocess.TimeoutExpired:
+      p.kill(); o = 'timeout'
+    outs.append((p.returncode, o))
+  return outs
+
+
+def test_hip_trainstate_world2_equals_the_full_batch_step(tmp_path):
+  import socket
+  import torch
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  o1, o2 = str(tmp_path / 'w1.pt'), str(tmp_path / 'w2.pt')
+  r1 = _launch(1, o1, port)
+  assert r1[0][0] == 0, r1[0][1][-3000:]
+  r2 = _launch(2, o2, port)
+  assert all(rc == 0 for rc, _ in r2), '\\n'.join(o[-2000:] for _, o in r2)
+  a, b = torch.load(o1, weights_only=True), torch.load(o2, weights_only=True)
+  diff = float((a['flat'] - b['flat']).abs().max())
+  print('world 1 vs world 2: max |param diff|', diff, 'losses', a['losses'], b['losses'], 'grad norms', a['gn'], b['gn'])
+  assert diff < 2e-5   # two AdamW steps at lr 1e-2 on fp32 buffers; gradients differ by summation order only
+  for x, y in zip(a['losses'], b['losses']):
+    assert abs(x - y) <= 1e-5 * abs(x)
+  assert abs(a['gn'] - b['gn']) <= 1e-4 * abs(a['gn'])
