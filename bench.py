@@ -88,7 +88,7 @@ def pmc_tables():
   """Per-kernel FETCH_SIZE / WRITE_SIZE totals of the committed rocprofv3 --pmc passes of this same command (separate passes, KiB
   units; `tools/profile_round.sh`).  Newest round first."""
   import csv
-  for tag in ('r02', 'r01'):
+  for tag in ('r03', 'r02', 'r01'):
     f_fetch = os.path.join(ROOT, 'profiles', f'{tag}_bench_b64_pmc_fetch.csv'); f_write = os.path.join(ROOT, 'profiles', f'{tag}_bench_b64_pmc_write.csv')
     if os.path.exists(f_fetch) and os.path.exists(f_write):
       rows = list(csv.DictReader(open(f_fetch))) + list(csv.DictReader(open(f_write)))
@@ -281,7 +281,7 @@ def main():
   dino, depth, precision = cfg['dino'], cfg['depth'], cfg['precision']
   fdt = torch.bfloat16 if precision == 'bf16' else torch.float32
   model = spa3d.TrackAutoEncoder3D(num_output_frames=T, dino_feature_dim=max(dino, 1), depth_feature_dim=max(depth, 1), use_dino=dino > 0,
-                                   use_depth=depth > 0, precision=precision)
+                                   use_depth=depth > 0, precision=precision, workspace_fraction=float(os.environ.get('SPA3D_WS_FRACTION', 0.80)))
   batch = synth_batch(B, N, Q, T, dino, depth, dev, seed=1234 + rank, feat_dtype=fdt)
   params = model.init(0, batch)['params']  # TrainState broadcasts rank 0's parameters: replicas start identical whatever the seed
   state = spa3d.TrainState(model, params, learning_rate=1e-4, warmup_steps=10000, total_steps=1000000)
