@@ -184,3 +184,35 @@ def test_16bit_gradients_agree_with_fp32_along_the_fp32_trajectory(precision):
   else:
     assert min(cosines) >= 0.999   # measured min 0.99946: (1 - cos) six times smaller than bf16's
     assert worst[0] <= 0.10, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', [4, 5])
+def test_single_orientation_attention_backward_in_model_ragged(mode):
+  """The opt-in single-orientation attention backward (attn_bwd_mode 4: 8 waves, 5: 12 waves) inside the full-size model on RAGGED sequences (token
+  pruning: case c772 has boundary_frame = (150, 97) and 10 % occlusion, so sequence lengths differ and whole key tiles past a sequence's end must
+  read as zeros in the dS image) against the default two-role kernel: every gradient leaf, fp16 (the sharp statement, as in
+  test_token_pruning_equals_the_dense_encoder)."""
+  import spa3d
+  sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+  import make_t150_golden as G
+  cfg, p, batch, noise = G.make_inputs('c772')
+  lib = spa3d._lib.load()
+  runs = {}
+  for m in (1, mode):
+    model = product_model(spa3d, cfg, 'fp16')
+    gb = batch_to(batch, 'cuda')
+    for k in ('dino_features', 'depth_features'):
+      gb[k] = gb[k].half()
+    gp = O.tree_map(lambda t: t.cuda(), p)
+    h = model._handle(768, 1)[0]
+    spa3d._lib.check(lib.spa3d_set_option(h, b'attn_bwd_mode', float(m)), h)
+    ld, grads, preds = model.loss_and_grads({'params': gp}, gb, noise=noise.cuda(), return_predictions=True)
+    torch.cuda.synchronize()
+    runs[m] = (float(ld['total_loss']), {k: v.clone() for k, v in O.tree_flatten(grads).items()})
+  (l1, g1), (l4, g4) = runs[1], runs[mode]
+  worst = max((rel_err(g4[k], g1[k]), k) for k in g1 if float(g1[k].double().norm()) > 1e-12)
+  print(f'attention backward mode {mode} vs 1 in-model (ragged, fp16): loss {l4} vs {l1}; worst gradient leaf {worst}')
+  assert l4 == l1  # the forward is the same code
+  assert all(bool(torch.isfinite(v).all()) for v in g4.values())
+  assert worst[0] < 0.04
