@@ -213,6 +213,6 @@ def test_single_orientation_attention_backward_in_model_ragged(mode):
   (l1, g1), (l4, g4) = runs[1], runs[mode]
   worst = max((rel_err(g4[k], g1[k]), k) for k in g1 if float(g1[k].double().norm()) > 1e-12)
   print(f'attention backward mode {mode} vs 1 in-model (ragged, fp16): loss {l4} vs {l1}; worst gradient leaf {worst}')
-  assert l4 == l1  # the forward is the same code
+  assert abs(l4 - l1) <= 1e-6 * abs(l1)  # the forward is the same code (the loss sums are float atomics: last-bit differences run to run)
   assert all(bool(torch.isfinite(v).all()) for v in g4.values())
   assert worst[0] < 0.04
