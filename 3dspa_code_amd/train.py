@@ -161,7 +161,26 @@ class TrainState:
       # which the next spa3d_loss_and_grads on this handle applies (include/spa3d.h)
       h = model._handle(*model._dims_from_params(self.params))[0]
       _lib.check(_lib.load().spa3d_set_loss_scale_state(h, self.scratch.data_ptr() + 16), h, 'spa3d_set_loss_scale_state')
+      self._scale_state_on = True
     self.sync_from_rank0()
+
+  def close(self):
+    """Detach what this state registered on the model's handle (gradient-segment events, the loss-scale state in `scratch`): the handle
+    outlives the state (it belongs to the model), the events and the scratch buffer do not."""
+    try:
+      lib = _lib.load()
+      h = self.model._handle(*self.model._dims_from_params(self.params))[0]
+      if getattr(self, '_overlap', None) is not None:
+        lib.spa3d_set_grad_events(h, None, None)
+        self._overlap = None
+      if getattr(self, '_scale_state_on', False):
+        lib.spa3d_set_loss_scale_state(h, None)
+        self._scale_state_on = False
+    except Exception:
+      pass
+
+  def __del__(self):
+    self.close()
 
   def sync_from_rank0(self):
     """parameters + Adam moments of every replica := rank 0's (also after load_train_state on rank 0 only)"""
