@@ -116,3 +116,31 @@ def test_lr_schedule_matches_oracle(spa3d):
   f = spa3d.create_learning_rate_schedule(1e-4, 10000, 1000000)
   for s in (0, 1, 9999, 10000, 10001, 500000, 1000000, 2000000):
     assert abs(f(s) - O.lr_schedule(s, 1e-4, 10000, 1000000)) < 1e-18
+
+
+def test_options_plan_stats_and_gradient_segments(spa3d):
+  """Round-3 additions to the boundary (no compute): per-handle options refuse unknown names, plan statistics start at zero, and the three
+  gradient segments (spa3d_grad_segments: the order in which the flat gradient buffer becomes final in the last chunk's backward) tile the
+  buffer at leaf boundaries with the Flax module groups on the documented sides."""
+  lib = spa3d._lib.load()
+  m = spa3d.TrackAutoEncoder3D(precision='bf16')
+  h, leaves, n = m._handle(768, 1)
+  assert lib.spa3d_set_option(h, b'prune', 0.0) == 0 and lib.spa3d_set_option(h, b'ro_share', 1.0) == 0
+  assert lib.spa3d_set_option(h, b'no_such_option', 1.0) == 1 and b'unknown option' in lib.spa3d_last_error(h)
+  assert lib.spa3d_set_option(h, b'loss_scale', 2.0) == 1  # fp16 handles only
+  o = (C.c_double * 4)()
+  assert lib.spa3d_plan_stats(h, o) == 0 and list(o) == [0.0, 0.0, 0.0, 0.0]
+  b4 = (C.c_int64 * 4)()
+  assert lib.spa3d_grad_segments(h, b4) == 0
+  b = list(b4)
+  assert b[0] == 0 and b[3] == n and 0 < b[1] < b[2] < n
+  offs = {name: off for name, _, off in leaves}
+  assert b[1] == min(off for name, off in offs.items() if name.startswith('tracks_to_latents/'))
+  assert b[2] == min(off for name, off in offs.items() if name.startswith('track_readout_attn/'))
+  for name, off in offs.items():
+    top = name.split('/')[0]
+    seg = 0 if off < b[1] else (1 if off < b[2] else 2)
+    want = {'initializer': 0, 'input_readout_token': 0, 'track_token_projection': 0, 'dino_projection': 0, 'depth_projection': 0, 'input_track_transformer': 0,
+            'tracks_to_latents': 1, 'compressor': 1, 'decompressor': 1, 'decompress_attn': 1, 'track_readout_attn': 2, 'query_encoder': 2, 'track_predictor': 2}[top]
+    assert seg == want, name
+  assert lib.spa3d_set_grad_events(h, None, None) == 0 and lib.spa3d_set_loss_scale_state(h, None) == 0
