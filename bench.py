@@ -333,7 +333,9 @@ def main():
         'config': {'workload': cfg['name'] + ', fwd+loss+bwd+clip+AdamW' + (f' [overrides: B={B}, N={N}, Q={Q}, T={T}]' if (B, N, Q, T) != (cfg['B'], cfg['N'], cfg['Q'], cfg['T']) else ''),
                    'baseline_config': args.config, 'per_gpu_batch': B, 'global_batch': B * world, 'support': N, 'query': Q,
                    'frames': T, 'channels': C, 'parallelism': f'dp{world}', 'chunk_samples': int(os.environ.get('SPA3D_CHUNK', 0)),
-                   'final_loss': loss, **plan},
+                   'final_loss': loss, **plan,
+                   'grad_allreduce': ('none (1 rank)' if world == 1 else ('RCCL SUM, overlapped with the last chunk\'s backward (3 segments)' if state._overlap is not None
+                                                                            else 'RCCL SUM after the backward'))},
         'roofline': roof,
     }
     if args.config in F_REF_FWD_PER_STEP_B64:
