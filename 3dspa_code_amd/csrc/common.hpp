@@ -156,6 +156,7 @@ struct spa3d_ctx {
   int nt_8p = 1;      // 8-phase kernels (256x256 / 128x384, counted vmcnt, staggered wave rows); 2 = also for small M, 0/3 = off
   int tn_8p = 1;      // 8-phase TN (dW) kernels; SPA3D_TN_8P=0 disables, =2 forces (tests)
   int tn_qp = 2;      // quarters (16 reduction rows) per phase of the 8-phase TN kernels: 2 = 16 MFMAs per barrier pair (+7-10 %), 1 = 8
+  int tn_seg = 1;     // dW of a fused q | k | v projection as ONE 8-phase TN GEMM with segmented outputs (SPA3D_TN_SEG=0: one GEMM per segment)
   int tn_rounds = 0;  // 0: M-split count of the 8-phase TN kernels from the makespan model; > 0: 256 * rounds / tiles (experiments)
   int nt_8pp = 1;     // persistent form of the 256x256 8-phase NT kernel (SPA3D_NT_8PP=0 disables): +3-6 %
   int nt_coarse = 1;  // persistent NT kernel with two phases per K-tile (32 MFMAs per barrier pair) instead of four (SPA3D_NT_COARSE)
@@ -213,6 +214,9 @@ struct GemmDesc {
   int32_t brow_group = 0, brow_skip = 0;  // same remap on B's k index (dW over token rows that skip the readout row)
   void* pre_out = nullptr;                // with EPI_GELU: the pre-activation (T, C layout) is stored here as well
   const void* zero_page = nullptr;        // >= 16 B of zeros (tiled TN kernel: rows past the end of the reduction)
+  int32_t seg_n = 0; void* C_seg[2] = {nullptr, nullptr};  // tiled TN (dW) only: output columns in seg_n-wide segments, segment s >= 1 in C_seg[s-1]
+                                                          // (the q / k / v kernels of a fused projection are separate leaves); gemm_tn_bf16 returns
+                                                          // false when it cannot honour it
 };
 
 namespace SPA_NS {

@@ -1001,6 +1001,9 @@ struct TnArgs {
   int tiles_i, tiles_n, splits; int64_t rows_per_split;
   int brow_group, brow_skip;
   float* colsum;  // 8-phase kernels only: colsum[n] += sum_m B[m][n] (the bias gradient), nullptr = off
+  // 8-phase kernels only: the N output columns are seg_n-wide segments that live in different buffers (the q / k / v kernels of a fused
+  // projection are separate leaves): columns [s seg_n, (s+1) seg_n) go to Cseg[s - 1] for s >= 1, row stride ldc in each.  0 = one buffer.
+  int seg_n; float* Cseg[2];
 };
 
 __device__ __forceinline__ uint2 ds_read_tr16_b64(const void* p) {
@@ -1311,11 +1314,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs g) {
   for (int i = 0; i < WIT; ++i)
 #pragma unroll
     for (int j = 0; j < WNT; ++j) {
-      const int gn = n0 + wc * (WNT * 32) + j * 32 + col;
+      const int gn0 = n0 + wc * (WNT * 32) + j * 32;   // wave-uniform: a 32-column group never straddles a segment (seg_n % 32 == 0)
+      float* cb = g.C; int cn = gn0 + col;
+      if (g.seg_n > 0) { const int sg = gn0 / g.seg_n; if (sg > 0) { cb = g.Cseg[sg > 1]; cn -= sg * g.seg_n; } }
+      const int gn = gn0 + col;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int gi = i0 + wr * (WIT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rb;
-        if (gi < g.Ki && gn < g.N) atomicAdd(g.C + (int64_t)gi * g.ldc + gn, acc[i][j][r]);
+        if (gi < g.Ki && gn < g.N) atomicAdd(cb + (int64_t)gi * g.ldc + cn, acc[i][j][r]);
       }
     }
 }
@@ -1367,6 +1373,8 @@ bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d) {
   g.M = M; g.Ki = Ki; g.N = N; g.lda = d.sAk; g.ldb = d.sBk; g.ldc = d.sCm;
   g.tiles_i = (Ki + 127) / 128; g.tiles_n = (N + 127) / 128;
   g.brow_group = d.brow_group; g.brow_skip = d.brow_skip; g.colsum = nullptr;
+  g.seg_n = d.seg_n; g.Cseg[0] = (float*)d.C_seg[0]; g.Cseg[1] = (float*)d.C_seg[1];
+  if (d.seg_n > 0 && (d.seg_n % 32 || N % d.seg_n || N / d.seg_n > 3 || d.colsum_out)) return false;
   c->tn_colsum_fused = false;
   if (c->tn_8p && (M >= 65536 || c->tn_8p == 2) && (g.brow_group == 0 || g.brow_group >= 16)) {
     // tile shape with the least padding: 384 x 128 / 128 x 384 when one dimension is an odd multiple of 384, else 256 x 256
@@ -1385,6 +1393,7 @@ bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d) {
       return true;
     }
   }
+  if (d.seg_n > 0) return false;  // segmented outputs exist in the 8-phase kernels only: the caller falls back to one GEMM per segment
   const int64_t tiles = (int64_t)g.tiles_i * g.tiles_n;
   // enough workgroups to fill 256 CUs several times over, but >= 4096 reduction rows per split so the
   // f32 atomic traffic (4 B per output element per split) stays a few % of the tile's MFMA time

@@ -191,6 +191,18 @@ template <typename T> struct Net {
   }
   // gw += X^T dY ; gb += colsum(dY)
   void lin_bwd_w(const Lin<T>& l, const T* X, const T* dY, int64_t M, int64_t ldx = 0, int brow_group = 0, int brow_skip = 0) {
+    if constexpr (sizeof(T) == 2) {
+      // fused projections (q | k | v): ONE dW GEMM over all segments -- X is read once instead of once per segment, a third of the launches --
+      // with the output tiles routed to the segments' separate leaves (8-phase TN kernels; else the per-segment loop below)
+      if (l.nseg > 1 && !l.gb && c->gemm_impl != 1 && c->tn_seg && l.gw[0]) {
+        GemmDesc d{};
+        d.A = X; d.B = dY; d.C = l.gw[0]; d.M = l.K; d.N = l.N; d.K = M;
+        d.sAm = 1; d.sAk = ldx ? ldx : l.K; d.sBk = l.N; d.sBn = 1; d.sCm = l.segw;
+        d.out_f32 = 1; d.accumulate = 1; d.zero_page = zero_page; d.brow_group = brow_group; d.brow_skip = brow_skip;
+        d.seg_n = l.segw; d.C_seg[0] = l.gw[1]; d.C_seg[1] = l.nseg > 2 ? l.gw[2] : nullptr;
+        if (gemm_tn_bf16(c, d)) return;
+      }
+    }
     for (int s = 0; s < l.nseg; ++s) {
       GemmDesc d{};
       d.A = X; d.B = dY + (int64_t)s * l.segw; d.C = l.gw[s]; d.M = l.K; d.N = l.segw; d.K = M;
@@ -886,6 +898,7 @@ int spa3d_create(const spa3d_config* cfg, spa3d_handle* out) {
   e = getenv("SPA3D_TN_8P"); if (e) c->tn_8p = atoi(e);
   e = getenv("SPA3D_TN_QP"); if (e) c->tn_qp = atoi(e);
   e = getenv("SPA3D_TN_ROUNDS"); if (e) c->tn_rounds = atoi(e);
+  e = getenv("SPA3D_TN_SEG"); if (e) c->tn_seg = atoi(e);
   *out = c;
   return SPA3D_OK;
 }
