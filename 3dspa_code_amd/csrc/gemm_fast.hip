@@ -435,8 +435,10 @@ __device__ __forceinline__ void nt_store4(const NtArgs& g, int64_t gm, int gn, c
 
 // WMT x WNT = 16x16 output tiles per wave; waves 2(M) x 4(N); tile = (32 WMT) x (64 WNT): <8,4> = 256x256, <4,6> = 128x384
 // (N = 384 in ONE tile: the A panel is read from HBM exactly once).  64 KiB per LDS buffer in both.
+// <4,2> = 128x128 on 80 KiB of LDS and <= 128 registers: TWO workgroups per CU, so one's epilogue (the store drain that is purely additive at
+// K = 384) can run under the other's K-loop -- the round-3 measurement of that hypothesis (SPA3D_NT_8P=42)
 template <int WMT, int WNT, bool COARSE = false>
-__global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(NtArgs g) {
+__global__ __launch_bounds__(512, (WMT * WNT <= 8 ? 4 : 2)) void gemm_nt8p_kernel(NtArgs g) {
   constexpr int BM = 32 * WMT, BN = 64 * WNT;
   constexpr int NA = WMT / 4, NB = WNT / 2;   // LDS-DMA per thread per A / B half-tile
   constexpr int HM = WMT / 2, HN = WNT / 2;   // tiles per quadrant side
@@ -582,8 +584,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(NtArgs g) {
   // back as 8 columns per lane, rows contiguous: every store instruction writes whole 128-B / 192-B row segments.
   constexpr int RB = WNT * 64;           // row bytes
   constexpr int CPR = WNT * 2;           // 8-column groups per row
-  char* reg = smem + w * 16384;
-  auto swz = [](int chunk, int row) { return WNT == 4 ? (chunk ^ (row & 15)) : ((chunk & ~7) | ((chunk & 7) ^ ((row >> 1) & 7))); };
+  constexpr int EPI_STRIDE = ((3 * BM + 2 * BN) * 128 / 8) & ~1023;  // an eighth of the kernel's LDS per wave (>= its 8 WMT x 64 WNT byte region)
+  static_assert(EPI_STRIDE >= 8 * WMT * WNT * 64, "epilogue region");
+  char* reg = smem + w * EPI_STRIDE;
+  auto swz = [](int chunk, int row) { return WNT == 4 ? (chunk ^ (row & 15)) : WNT == 2 ? (chunk ^ (row & 7)) : ((chunk & ~7) | ((chunk & 7) ^ ((row >> 1) & 7))); };
   constexpr int NIT = WMT * WNT / 4;
   // residual / pre-activation operand: ALL of the tile's loads go out before the first store (vmcnt retires in order: a load issued
   // after the first half's stores would be waited for together with their drain); 2 NIT x 4 VGPRs, the K-loop's fragments are dead
@@ -954,7 +958,7 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   const int KT = d.K / 64;
   // 8-phase kernels: 256x256 when 256 | N, 128x384 when 384 | N (see the kernel header for the measurements)
   if (c->nt_8p && (d.N % 256 == 0 || d.N % 384 == 0) && (d.M >= 256 * 64 || c->nt_8p == 2) && c->nt_8p != 3) {
-    const bool pers_ok = c->nt_8pp && c->nt_8p != 44 && d.K >= 128 && !d.accumulate && d.crow_group == 0 && d.M % 8 == 0 &&
+    const bool pers_ok = c->nt_8pp && c->nt_8p != 44 && c->nt_8p != 42 && d.K >= 128 && !d.accumulate && d.crow_group == 0 && d.M % 8 == 0 &&
                          (!d.aux || (c->nt_8pp != 3 && !d.pre_out && !d.out_f32));
     if (pers_ok && d.N % 256 == 0) {  // persistent 256x256 (accumulate would add loads to the counted wait)
       NtArgs g2 = g; g2.tiles_m = (int)((g.M + 255) / 256); g2.tiles_n = g.N / 256;
@@ -978,7 +982,8 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
       }
       if (d.aux) gemm_nt8pp_kernel<4, 6, false, true><<<256, 512, 163840, c->stream>>>(g2);
       else gemm_nt8pp_kernel<4, 6, false, false><<<256, 512, 163840, c->stream>>>(g2);
-    } else if (d.N % 256 == 0) { if (c->nt_8p == 44) launch_nt8p<4, 4>(c, g); else launch_nt8p<8, 4>(c, g); } else launch_nt8p<4, 6>(c, g);
+    } else if (c->nt_8p == 42 && d.N % 128 == 0) launch_nt8p<4, 2>(c, g);
+    else if (d.N % 256 == 0) { if (c->nt_8p == 44) launch_nt8p<4, 4>(c, g); else launch_nt8p<8, 4>(c, g); } else launch_nt8p<4, 6>(c, g);
     SPA_LAUNCH_CHECK(c);
     return true;
   }
