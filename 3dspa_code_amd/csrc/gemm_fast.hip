@@ -957,7 +957,7 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   ps.tag(d.M, d.N, d.K, d.epi | (d.aux ? 4 : 0) | (d.pre_out ? 8 : 0) | (d.out_f32 ? 16 : 0) | (d.accumulate ? 32 : 0) | (d.crow_group ? 64 : 0) | (d.sAm != d.K ? 128 : 0));
   const int KT = d.K / 64;
   // 8-phase kernels: 256x256 when 256 | N, 128x384 when 384 | N (see the kernel header for the measurements)
-  if (c->nt_8p && (d.N % 256 == 0 || d.N % 384 == 0) && (d.M >= 256 * 64 || c->nt_8p == 2) && c->nt_8p != 3) {
+  if (c->nt_8p && (d.N % 256 == 0 || d.N % 384 == 0 || (c->nt_8p == 42 && d.N % 128 == 0)) && (d.M >= 256 * 64 || c->nt_8p == 2 || c->nt_8p == 42) && c->nt_8p != 3) {
     const bool pers_ok = c->nt_8pp && c->nt_8p != 44 && c->nt_8p != 42 && d.K >= 128 && !d.accumulate && d.crow_group == 0 && d.M % 8 == 0 &&
                          (!d.aux || (c->nt_8pp != 3 && !d.pre_out && !d.out_f32));
     if (pers_ok && d.N % 256 == 0) {  // persistent 256x256 (accumulate would add loads to the counted wait)

@@ -436,6 +436,14 @@ def test_linear_tiled_nt_8phase(lib, monkeypatch, M, N, K, act, res, bias):
   test_linear_tiled_nt(lib, M, N, K, act, res, bias)
 
 
+@pytest.mark.parametrize('M,N,K,act,res,bias', [(256, 256, 128, 0, False, True), (513, 512, 384, 1, True, True), (1024, 2304, 384, 0, False, False),
+                                                (1500, 1280, 768, 0, True, True), (777, 768, 64, 0, False, True), (130, 128, 128, 0, False, True), (4133, 1536, 192, 1, False, True)])
+def test_linear_tiled_nt_8phase_two_workgroups_per_cu(lib, monkeypatch, M, N, K, act, res, bias):
+  """the 8-phase schedule at 128 x 128 tiles, two workgroups per CU (SPA3D_NT_8P=42: the round-3 store-drain-overlap experiment, opt-in, rejected by measurement)"""
+  monkeypatch.setenv('SPA3D_NT_8P', '42')
+  test_linear_tiled_nt(lib, M, N, K, act, res, bias)
+
+
 @pytest.mark.parametrize('M,N,K,act,res,bias', [(70001, 512, 256, 0, True, True), (70008, 512, 256, 0, True, True), (140000, 256, 128, 1, False, True), (66000, 768, 384, 0, False, False),
                                                 (4133, 2304, 384, 0, True, False), (256 * 300, 512, 192, 0, True, True), (9000, 1280, 768, 1, False, True),
                                                 (70008, 384, 256, 0, True, True), (66000, 1152, 384, 1, False, True), (140000, 384, 128, 0, False, False),
