@@ -162,6 +162,9 @@ struct spa3d_ctx {
   int nt_coarse = 1;  // persistent NT kernel with two phases per K-tile (32 MFMAs per barrier pair) instead of four (SPA3D_NT_COARSE)
   int nt_stream = 1;  // non-temporal stores for bf16 GEMM outputs >= 512 MB (SPA3D_NT_STREAM=0 disables)
   int nt_occ = 1;     // single-buffer 4-workgroups/CU NT kernel for K <= 512 (SPA3D_NT_OCC=0 disables)
+  bool ln_folded = false;        // set by gemm_nt_bf16: the last call also produced GemmDesc::ln_out / ln_stats
+  int ln_fold = 0;               // LayerNorm forward folded into the epilogue of the preceding N = 384 GEMM (SPA3D_LN_FOLD=1): bit-identical outputs, measured
+                                 // net zero (LayerNorm class -10.5 ms/step, NT GEMM class +10-12), so off by default
   bool tn_colsum_fused = false;  // set by gemm_tn_bf16: the last call also produced GemmDesc::colsum_out
   Prof prof;
 };
@@ -214,6 +217,10 @@ struct GemmDesc {
   int32_t brow_group = 0, brow_skip = 0;  // same remap on B's k index (dW over token rows that skip the readout row)
   void* pre_out = nullptr;                // with EPI_GELU: the pre-activation (T, C layout) is stored here as well
   const void* zero_page = nullptr;        // >= 16 B of zeros (tiled TN kernel: rows past the end of the reduction)
+  // tiled NT with N == 384 (the 128 x 384-tile kernel owns whole rows): also emit LayerNorm(C) * ln_scale (no bias, eps 1e-6, fast variance; statistics
+  // of the 16-bit-rounded C, exactly what the stand-alone kernel would read back) and its (mean, rstd) rows; the callee reports it in
+  // spa3d_ctx::ln_folded, otherwise the caller runs k_layernorm itself
+  void* ln_out = nullptr; float* ln_stats = nullptr; const float* ln_scale = nullptr;
   int32_t seg_n = 0; void* C_seg[2] = {nullptr, nullptr};  // tiled TN (dW) only: output columns in seg_n-wide segments, segment s >= 1 in C_seg[s-1]
                                                           // (the q / k / v kernels of a fused projection are separate leaves); gemm_tn_bf16 returns
                                                           // false when it cannot honour it

@@ -46,6 +46,7 @@ struct NtArgs {
   int ablate;
 #endif
   int nt_store;  // bf16 output with non-temporal stores: a streamed output far larger than the caches (+3-6 % measured at K = 384)
+  bf16_t* ln_out; float* ln_stats; const float* ln_scale;  // 128 x 384-tile kernel only (GemmDesc::ln_out)
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
@@ -621,6 +622,97 @@ __global__ __launch_bounds__(512, (WMT * WNT <= 8 ? 4 : 2)) void gemm_nt8p_kerne
     if (g.bias && gn < g.N) { const float4 b0 = *(const float4*)(g.bias + gn), b1 = *(const float4*)(g.bias + gn + 4);
       bv[it][0] = b0.x; bv[it][1] = b0.y; bv[it][2] = b0.z; bv[it][3] = b0.w; bv[it][4] = b1.x; bv[it][5] = b1.y; bv[it][6] = b1.z; bv[it][7] = b1.w; }
   }
+  if constexpr (WMT == 4 && WNT == 6) {
+    // ---- LayerNorm folded into this epilogue (the tile holds whole 384-wide rows; a row's columns sit in the four waves of a wave-row).
+    // Per half: (A) final values (bias, residual) -> C, and their 16-bit-rounded copies back into the wave's region; (B) lanes 0..31 sum
+    // their row's 96 values, partial (sum, sum of squares) into the wave's slack behind its region; workgroup barrier; (C) every lane
+    // combines the four partials of its row and writes LN(row) * scale; wave-column 0 writes (mean, rstd).  Host guarantees: N == 384,
+    // no GELU / f32 output / accumulate / row remap.  The scale vector is staged in LDS before the first store (a load issued behind the
+    // stores would wait for their drain: vmcnt retires in order).
+    if (g.ln_out) {
+      static_assert(EPI_STRIDE >= 12288 + 512 + 384, "slack for the LayerNorm partials and the scale slice");
+      float2* mypart = (float2*)(reg + 12288);          // [2 halves][32 rows]
+      float* mysc = (float*)(reg + 12288 + 512);        // this wave's 96 scale values
+      for (int t = lane; t < 96; t += 64) mysc[t] = g.ln_scale[wc * 96 + t];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int i = 0; i < HM; ++i)
+#pragma unroll
+          for (int j = 0; j < WNT; ++j) *(f32x4*)(reg + (i * 16 + fr) * RB + (swz(j * 4 + fq, i * 16 + fr) << 4)) = acc[half * HM + i][j];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {  // (A)
+          const int id = it * 64 + lane, row = id / CPR, c8 = id - row * CPR;
+          f32x4* p0 = (f32x4*)(reg + row * RB + (swz(2 * c8, row) << 4)); f32x4* p1 = (f32x4*)(reg + row * RB + (swz(2 * c8 + 1, row) << 4));
+          const f32x4 v0 = *p0, v1 = *p1;
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          const int64_t gm = m0 + wr * (WMT * 16) + half * (WMT * 8) + row;
+          const int gn = wc * (WNT * 16) + c8 * 8;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = g.alpha * v[r] + bv[it][r];
+          if (g.aux) {
+            const unsigned* xp = (const unsigned*)&auxv[half][it];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[2 * r] += unpack_lo(xp[r]); v[2 * r + 1] += unpack_hi(xp[r]); }
+          }
+          uint4 o4; unsigned* op = (unsigned*)&o4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) op[r] = (unsigned)f2bf(v[2 * r]) | ((unsigned)f2bf(v[2 * r + 1]) << 16);
+          if (gm < g.M) {
+            uint4* cp = (uint4*)((bf16_t*)g.C + gm * g.ldc + gn);
+            if (g.nt_store) { typedef __attribute__((ext_vector_type(4))) unsigned u32x4; __builtin_nontemporal_store(u32x4{o4.x, o4.y, o4.z, o4.w}, (u32x4*)cp); }
+            else *cp = o4;
+          }
+          *p0 = f32x4{unpack_lo(op[0]), unpack_hi(op[0]), unpack_lo(op[1]), unpack_hi(op[1])};   // what the stand-alone LayerNorm would read back
+          *p1 = f32x4{unpack_lo(op[2]), unpack_hi(op[2]), unpack_lo(op[3]), unpack_hi(op[3])};
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 32) {  // (B) row `lane` of this half: 24 chunks of 4 columns
+          float s_ = 0.f, ss_ = 0.f;
+#pragma unroll
+          for (int ch = 0; ch < 4 * WNT; ++ch) {
+            const f32x4 t = *(const f32x4*)(reg + lane * RB + (swz(ch, lane) << 4));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s_ += t[r]; ss_ += t[r] * t[r]; }
+          }
+          mypart[half * 32 + lane] = float2{s_, ss_};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {  // (C)
+          const int id = it * 64 + lane, row = id / CPR, c8 = id - row * CPR;
+          float s_ = 0.f, ss_ = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float2 pj = ((const float2*)(smem + (wr * 4 + j) * EPI_STRIDE + 12288))[half * 32 + row];
+            s_ += pj.x; ss_ += pj.y;
+          }
+          const float mu = s_ * (1.f / 384.f);
+          const float var = fmaxf(ss_ * (1.f / 384.f) - mu * mu, 0.f);
+          const float rs = rsqrtf(var + 1e-6f);
+          const f32x4 v0 = *(const f32x4*)(reg + row * RB + (swz(2 * c8, row) << 4));
+          const f32x4 v1 = *(const f32x4*)(reg + row * RB + (swz(2 * c8 + 1, row) << 4));
+          const f32x4 s0 = *(const f32x4*)(mysc + c8 * 8), s1 = *(const f32x4*)(mysc + c8 * 8 + 4);
+          const int64_t gm = m0 + wr * (WMT * 16) + half * (WMT * 8) + row;
+          const int gn = wc * (WNT * 16) + c8 * 8;
+          uint4 o4; unsigned* op = (unsigned*)&o4;
+          op[0] = (unsigned)f2bf((v0[0] - mu) * rs * s0[0]) | ((unsigned)f2bf((v0[1] - mu) * rs * s0[1]) << 16);
+          op[1] = (unsigned)f2bf((v0[2] - mu) * rs * s0[2]) | ((unsigned)f2bf((v0[3] - mu) * rs * s0[3]) << 16);
+          op[2] = (unsigned)f2bf((v1[0] - mu) * rs * s1[0]) | ((unsigned)f2bf((v1[1] - mu) * rs * s1[1]) << 16);
+          op[3] = (unsigned)f2bf((v1[2] - mu) * rs * s1[2]) | ((unsigned)f2bf((v1[3] - mu) * rs * s1[3]) << 16);
+          if (gm < g.M) {
+            uint4* yp = (uint4*)(g.ln_out + gm * 384 + gn);
+            if (g.nt_store) { typedef __attribute__((ext_vector_type(4))) unsigned u32x4; __builtin_nontemporal_store(u32x4{o4.x, o4.y, o4.z, o4.w}, (u32x4*)yp); }
+            else *yp = o4;
+            if (wc == 0 && c8 == 0) *(float2*)(g.ln_stats + gm * 2) = float2{mu, rs};
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -943,6 +1035,8 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   g.bias = d.bias; g.aux = (const bf16_t*)d.aux; g.pre_out = (bf16_t*)d.pre_out; g.epi = d.epi; g.out_f32 = d.out_f32; g.accumulate = d.accumulate; g.alpha = d.alpha;
   g.tiles_m = (int)((d.M + 127) / 128); g.tiles_n = (d.N + 127) / 128;
   g.crow_group = d.crow_group; g.crow_skip = d.crow_skip;
+  g.ln_out = nullptr; g.ln_stats = nullptr; g.ln_scale = nullptr;
+  c->ln_folded = false;
 #ifdef SPA3D_ABLATE
   { const char* e = getenv("SPA3D_ABLATE"); g.ablate = e ? atoi(e) : 0; }
 #endif
@@ -983,7 +1077,15 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
       if (d.aux) gemm_nt8pp_kernel<4, 6, false, true><<<256, 512, 163840, c->stream>>>(g2);
       else gemm_nt8pp_kernel<4, 6, false, false><<<256, 512, 163840, c->stream>>>(g2);
     } else if (c->nt_8p == 42 && d.N % 128 == 0) launch_nt8p<4, 2>(c, g);
-    else if (d.N % 256 == 0) { if (c->nt_8p == 44) launch_nt8p<4, 4>(c, g); else launch_nt8p<8, 4>(c, g); } else launch_nt8p<4, 6>(c, g);
+    else if (d.N % 256 == 0) { if (c->nt_8p == 44) launch_nt8p<4, 4>(c, g); else launch_nt8p<8, 4>(c, g); }
+    else {
+      // LayerNorm of the output folded into the epilogue: whole rows in one tile, plain epilogue (bias / residual only)
+      if (d.ln_out && c->ln_fold && d.N == 384 && d.sCm == 384 && d.epi == EPI_NONE && !d.out_f32 && !d.accumulate && d.crow_group == 0 && !d.pre_out &&
+          d.alpha == 1.f && d.ln_stats && d.ln_scale && aligned16(d.ln_out)) {
+        g.ln_out = (bf16_t*)d.ln_out; g.ln_stats = d.ln_stats; g.ln_scale = d.ln_scale; c->ln_folded = true;
+      }
+      launch_nt8p<4, 6>(c, g);
+    }
     SPA_LAUNCH_CHECK(c);
     return true;
   }

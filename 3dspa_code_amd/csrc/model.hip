@@ -169,9 +169,13 @@ template <typename T> struct Net {
     gemm_generic<T>(c, d);
   }
   // Y[M,N] = epi(X[M,K] W + b) (+ residual)
+  struct LnOut { T* out; float* stats; const float* scale; };  // LayerNorm(Y) folded into the GEMM's epilogue where the kernel can (GemmDesc::ln_out)
   void lin_fwd(const Lin<T>& l, const T* X, void* Y, int64_t M, int epi = EPI_NONE, const T* residual = nullptr, int out_f32 = 0,
-               int accumulate = 0, int64_t ldx = 0, int64_t ldy = 0, int crow_group = 0, int crow_skip = 0, T* pre_out = nullptr) {
+               int accumulate = 0, int64_t ldx = 0, int64_t ldy = 0, int crow_group = 0, int crow_skip = 0, T* pre_out = nullptr,
+               const LnOut* ln = nullptr) {
     GemmDesc d{};
+    c->ln_folded = false;
+    if (ln) { d.ln_out = ln->out; d.ln_stats = ln->stats; d.ln_scale = ln->scale; }
     d.A = X; d.B = l.wn; d.C = Y; d.M = M; d.N = l.N; d.K = l.K;
     d.sAm = ldx ? ldx : l.K; d.sAk = 1; d.sBk = l.ldn; d.sBn = 1; d.sCm = ldy ? ldy : l.N;
     d.Bt = l.wt; d.ldBt = l.K;
@@ -252,7 +256,13 @@ template <typename T> struct Net {
     T* o = alloc<T>(Mg * E); float* lse = alloc<float>(M * H * 2);
     attn_fwd(qkv, qkv + E, qkv + 2 * E, 3 * E, 3 * E, 3 * E, w.sq, w.sk, km, nseq, S, S, o, lse, rg);  // :166-175
     T* a = alloc<T>(Mg * d);
-    lin_fwd(w.out, o, a, Mg, EPI_NONE, x);                                               // :178-183 + residual :79,90
+    T* na = nullptr; float* st2 = nullptr; bool ln2_folded = false;
+    if (!w.cross) {  // LayerNorm 2 (:103-105) rides in the out-projection's epilogue where the kernel owns whole rows (d = 384)
+      na = alloc<T>(Mg * d); st2 = alloc<float>(Mg * 2);
+      const LnOut ln{na, st2, w.norm_attn};
+      lin_fwd(w.out, o, a, Mg, EPI_NONE, x, 0, 0, 0, 0, 0, 0, nullptr, &ln);              // :178-183 + residual :79,90
+      ln2_folded = c->ln_folded;
+    } else lin_fwd(w.out, o, a, Mg, EPI_NONE, x);
     T *cq = nullptr, *ckv = nullptr, *co = nullptr; float* clse = nullptr;
     if (w.cross) {                                                                      // :92-100
       cq = alloc<T>(M * E); lin_fwd(w.cq, nq, cq, M);
@@ -261,8 +271,8 @@ template <typename T> struct Net {
       attn_fwd(cq, ckv, ckv + E, E, 2 * E, 2 * E, w.csq, w.csk, nullptr, nseq, S, Skv, co, clse);
       lin_fwd(w.cout, co, a, M, EPI_NONE, a);
     }
-    T* na = alloc<T>(Mg * d); float* st2 = alloc<float>(M * 2);
-    k_layernorm<T>(c, a, w.norm_attn, na, st2, M, d);                                   // :103-105
+    if (!na) { na = alloc<T>(Mg * d); st2 = alloc<float>(Mg * 2); }
+    if (!ln2_folded) k_layernorm<T>(c, a, w.norm_attn, na, st2, M, d);                  // :103-105
     T* hpre = alloc<T>(Mg * w.mlp); T* h = alloc<T>(Mg * w.mlp);
     lin_fwd(w.mlp_in, na, h, Mg, EPI_GELU, nullptr, 0, 0, 0, 0, 0, 0, hpre);             // :106  h = gelu(hpre), both kept for the backward
     lin_fwd(w.mlp_out, h, y, Mg, EPI_NONE, a);                                           // :107-108
@@ -899,6 +909,7 @@ int spa3d_create(const spa3d_config* cfg, spa3d_handle* out) {
   e = getenv("SPA3D_TN_QP"); if (e) c->tn_qp = atoi(e);
   e = getenv("SPA3D_TN_ROUNDS"); if (e) c->tn_rounds = atoi(e);
   e = getenv("SPA3D_TN_SEG"); if (e) c->tn_seg = atoi(e);
+  e = getenv("SPA3D_LN_FOLD"); if (e) c->ln_fold = atoi(e);
   *out = c;
   return SPA3D_OK;
 }

@@ -31,6 +31,9 @@ int op_linear(OpCtx& c, const T* A, const T* B, const float* bias, const T* res,
   d.bias = bias; d.epi = act ? EPI_GELU : EPI_NONE; d.aux = res;
   if constexpr (sizeof(T) == 2) {
     if (impl != 1) {
+      // measurement aid (tools/bench_ln_fold.py): a second output stream of the same size from the epilogue = what folding a LayerNorm's output
+      // into this GEMM would add to it
+      if (getenv("SPA3D_OP_PREOUT")) { d.pre_out = c.alloc<T>(M * N); if (c.ar.overflow) return SPA3D_ERR_WORKSPACE; }
       T* Bt = c.alloc<T>((int64_t)K * N);
       if (c.ar.overflow) return SPA3D_ERR_WORKSPACE;
       k_transpose<T>(&c, B, K, N, Bt);

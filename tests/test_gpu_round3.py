@@ -216,3 +216,31 @@ def test_single_orientation_attention_backward_in_model_ragged(mode):
   assert abs(l4 - l1) <= 1e-6 * abs(l1)  # the forward is the same code (the loss sums are float atomics: last-bit differences run to run)
   assert all(bool(torch.isfinite(v).all()) for v in g4.values())
   assert worst[0] < 0.04
+
+
+@pytest.mark.gpu
+def test_layernorm_folded_into_the_gemm_epilogue_equals_the_separate_kernel(monkeypatch):
+  """LayerNorm 2 of the track-encoder blocks (attention.py:103-105) computed in the epilogue of the out-projection GEMM (128 x 384 tiles own whole
+  rows; SPA3D_LN_FOLD, default on) against the stand-alone LayerNorm kernel, in-model at M >= 16 384 rows (case c772_tiles: the default dispatch takes
+  the 8-phase kernels).  Both normalise the same 16-bit-rounded values; only the summation order of the row statistics differs."""
+  import spa3d
+  sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+  import make_t150_golden as G
+  cfg, p, batch, noise = G.make_inputs('c772_tiles')
+  runs = {}
+  for fold in ('1', '0'):
+    monkeypatch.setenv('SPA3D_LN_FOLD', fold)
+    model = product_model(spa3d, cfg, 'bf16')
+    gb = batch_to(batch, 'cuda')
+    for k in ('dino_features', 'depth_features'):
+      gb[k] = gb[k].bfloat16()
+    gp = O.tree_map(lambda t: t.cuda(), p)
+    ld, grads, preds = model.loss_and_grads({'params': gp}, gb, noise=noise.cuda(), return_predictions=True)
+    lat = model.apply({'params': gp}, gb, method=model.encode)
+    torch.cuda.synchronize()
+    runs[fold] = (float(ld['total_loss']), {k: v.clone() for k, v in O.tree_flatten(grads).items()}, preds.tracks.clone(), lat.clone())
+  (l1, g1, t1, e1), (l0, g0, t0, e0) = runs['1'], runs['0']
+  worst = max((rel_err(g1[k], g0[k]), k) for k in g0 if float(g0[k].double().norm()) > 1e-12)
+  print(f'LayerNorm folded vs separate: latents rel {rel_err(e1, e0):.3e} tracks rel {rel_err(t1, t0):.3e} loss {l1} vs {l0}; worst gradient leaf {worst}')
+  assert rel_err(e1, e0) < 5e-3 and rel_err(t1, t0) < 5e-3 and abs(l1 - l0) < 1e-3 * abs(l0)
+  assert worst[0] < 0.12  # two bf16 runs that differ in the last bit of a few row statistics (cf. pruned vs dense: 0.19)
