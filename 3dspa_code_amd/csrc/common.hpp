@@ -158,7 +158,9 @@ struct spa3d_ctx {
   int tn_qp = 2;      // quarters (16 reduction rows) per phase of the 8-phase TN kernels: 2 = 16 MFMAs per barrier pair (+7-10 %), 1 = 8
   int tn_seg = 1;     // dW of a fused q | k | v projection as ONE 8-phase TN GEMM with segmented outputs (SPA3D_TN_SEG=0: one GEMM per segment)
   int tn_rounds = 0;  // 0: M-split count of the 8-phase TN kernels from the makespan model; > 0: 256 * rounds / tiles (experiments)
-  int nt_8pp = 1;     // persistent form of the 256x256 8-phase NT kernel (SPA3D_NT_8PP=0 disables): +3-6 %
+  int nt_8pp = 5;     // persistent forms of the 8-phase NT kernels (SPA3D_NT_8PP=0 disables; 1 = the 256x256 one only: +3-6 %).  5 (default since round 3) = also the
+                      // persistent 128x384 kernel: rejected in round 2 on a plain-epilogue micro-benchmark, but IN THE STEP its shapes carry a residual operand and it
+                      // wins on every one of them (out-projection 33.0 -> 27.8 ms/step, MLP-out 49.3 -> 44.0, plain dX shapes +1.5 %): NT class -17 ms/step
   int nt_coarse = 1;  // persistent NT kernel with two phases per K-tile (32 MFMAs per barrier pair) instead of four (SPA3D_NT_COARSE)
   int nt_stream = 1;  // non-temporal stores for bf16 GEMM outputs >= 512 MB (SPA3D_NT_STREAM=0 disables)
   int nt_occ = 1;     // single-buffer 4-workgroups/CU NT kernel for K <= 512 (SPA3D_NT_OCC=0 disables)

@@ -1066,7 +1066,7 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
       if (d.aux) gemm_nt8pp_kernel<8, 4, true, true><<<256, 512, 163840, c->stream>>>(g2);
       else if (c->nt_coarse) gemm_nt8pp_kernel<8, 4, true, false><<<256, 512, 163840, c->stream>>>(g2);
       else gemm_nt8pp_kernel<8, 4, false, false><<<256, 512, 163840, c->stream>>>(g2);
-    } else if (pers_ok && c->nt_8pp == 5 && !d.pre_out && !d.out_f32) {  // persistent 128x384: measured SLOWER than the non-persistent kernel (759 vs 840 TF/s at K = 768: 96-B row segments from the half-width epilogue passes), opt-in via SPA3D_NT_8PP=5
+    } else if (pers_ok && c->nt_8pp == 5 && !d.pre_out && !d.out_f32) {  // persistent 128x384 (SPA3D_NT_8PP=5, the default since round 3): slower than the non-persistent kernel on a PLAIN epilogue at K = 768 (759 vs 840 TF/s: 96-B row segments from the half-width epilogue passes), faster on every N = 384 shape of the step, whose epilogues mostly carry a residual (out-projection +19 %, MLP-out +12 %, dX shapes +1.5 %)
       NtArgs g2 = g; g2.tiles_m = (int)((g.M + 127) / 128); g2.tiles_n = g.N / 384;
       static bool attrq = false;
       if (!attrq) {

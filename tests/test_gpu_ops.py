@@ -433,6 +433,7 @@ def test_linear_tiled_nt_8phase(lib, monkeypatch, M, N, K, act, res, bias):
   """the 8-phase kernels (256x256 when 256 | N, 128x384 when 384 | N; counted vmcnt, staggered wave rows), forced on for any M with SPA3D_NT_8P=2;
   K = 64 / 128 / 192 exercise the prologue and tail paths of the schedule (1, 2, 3 K-tiles)"""
   monkeypatch.setenv('SPA3D_NT_8P', '2')
+  monkeypatch.setenv('SPA3D_NT_8PP', '1')  # (the 128x384 shapes on the NON-persistent kernel: the persistent one is the default since round 3)
   test_linear_tiled_nt(lib, M, N, K, act, res, bias)
 
 
