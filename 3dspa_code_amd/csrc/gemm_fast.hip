@@ -1054,7 +1054,9 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   if (c->nt_8p && (d.N % 256 == 0 || d.N % 384 == 0 || (c->nt_8p == 42 && d.N % 128 == 0)) && (d.M >= 256 * 64 || c->nt_8p == 2 || c->nt_8p == 42) && c->nt_8p != 3) {
     const bool pers_ok = c->nt_8pp && c->nt_8p != 44 && c->nt_8p != 42 && d.K >= 128 && !d.accumulate && d.crow_group == 0 && d.M % 8 == 0 &&
                          (!d.aux || (c->nt_8pp != 3 && !d.pre_out && !d.out_f32));
-    if (pers_ok && d.N % 256 == 0) {  // persistent 256x256 (accumulate would add loads to the counted wait)
+    static const int pref384 = [] { const char* e = getenv("SPA3D_NT_PREF384"); return e ? atoi(e) : 0; }();  // experiment: K <= pref384 and 384 | N -> the persistent 128x384 kernel
+    const bool use384 = pers_ok && c->nt_8pp == 5 && !d.pre_out && !d.out_f32 && d.N % 384 == 0 && (d.N % 256 != 0 || d.K <= pref384);
+    if (pers_ok && d.N % 256 == 0 && !use384) {  // persistent 256x256 (accumulate would add loads to the counted wait)
       NtArgs g2 = g; g2.tiles_m = (int)((g.M + 255) / 256); g2.tiles_n = g.N / 256;
       static bool attrp = false;
       if (!attrp) {
@@ -1066,7 +1068,7 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
       if (d.aux) gemm_nt8pp_kernel<8, 4, true, true><<<256, 512, 163840, c->stream>>>(g2);
       else if (c->nt_coarse) gemm_nt8pp_kernel<8, 4, true, false><<<256, 512, 163840, c->stream>>>(g2);
       else gemm_nt8pp_kernel<8, 4, false, false><<<256, 512, 163840, c->stream>>>(g2);
-    } else if (pers_ok && c->nt_8pp == 5 && !d.pre_out && !d.out_f32) {  // persistent 128x384 (SPA3D_NT_8PP=5, the default since round 3): slower than the non-persistent kernel on a PLAIN epilogue at K = 768 (759 vs 840 TF/s: 96-B row segments from the half-width epilogue passes), faster on every N = 384 shape of the step, whose epilogues mostly carry a residual (out-projection +19 %, MLP-out +12 %, dX shapes +1.5 %)
+    } else if (use384) {  // persistent 128x384 (SPA3D_NT_8PP=5, the default since round 3): slower than the non-persistent kernel on a PLAIN epilogue at K = 768 (759 vs 840 TF/s: 96-B row segments from the half-width epilogue passes), faster on every N = 384 shape of the step, whose epilogues mostly carry a residual (out-projection +19 %, MLP-out +12 %, dX shapes +1.5 %)
       NtArgs g2 = g; g2.tiles_m = (int)((g.M + 127) / 128); g2.tiles_n = g.N / 384;
       static bool attrq = false;
       if (!attrq) {
