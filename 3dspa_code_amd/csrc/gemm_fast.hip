@@ -1074,9 +1074,13 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
       if (!attrq) {
         (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<4, 6, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<4, 6, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<4, 6, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<4, 6, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         attrq = true;
       }
-      if (d.aux) gemm_nt8pp_kernel<4, 6, false, true><<<256, 512, 163840, c->stream>>>(g2);
+      static const int coarse384 = [] { const char* e = getenv("SPA3D_NT_COARSE384"); return e ? atoi(e) : 0; }();  // experiment: two-phase K-tiles in the persistent 128x384 kernel
+      if (coarse384) { if (d.aux) gemm_nt8pp_kernel<4, 6, true, true><<<256, 512, 163840, c->stream>>>(g2); else gemm_nt8pp_kernel<4, 6, true, false><<<256, 512, 163840, c->stream>>>(g2); }
+      else if (d.aux) gemm_nt8pp_kernel<4, 6, false, true><<<256, 512, 163840, c->stream>>>(g2);
       else gemm_nt8pp_kernel<4, 6, false, false><<<256, 512, 163840, c->stream>>>(g2);
     } else if (c->nt_8p == 42 && d.N % 128 == 0) launch_nt8p<4, 2>(c, g);
     else if (d.N % 256 == 0) { if (c->nt_8p == 44) launch_nt8p<4, 4>(c, g); else launch_nt8p<8, 4>(c, g); }
