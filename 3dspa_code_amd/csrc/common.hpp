@@ -68,9 +68,9 @@ __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
 // bf16-path variants (tiled GEMM epilogues only; the fp32 parity path keeps tanhf): gelu(x) = x*s, s = sigmoid(2u) = 1/(1+exp(-2u)),
 // gelu'(x) = s*(1 + 2x(1-s)u'), one v_exp_f32 + one v_rcp_f32 (abs error ~1e-7, far below bf16 rounding).
 __device__ __forceinline__ float gelu_sigmoid_2u(float x) {
-  const float c2 = 2.0f * 0.7978845608028654f;
-  const float u2 = c2 * (x + 0.044715f * x * x * x);
-  return __builtin_amdgcn_rcpf(1.0f + __expf(-u2));
+  // exp(-2u) = 2^(x (A + B x^2)) with A = -2 sqrt(2/pi) log2(e), B = 0.044715 A: one fma and two multiplies feed v_exp_f32 directly
+  constexpr float A = (float)(-2.0 * 0.7978845608028654 * 1.4426950408889634), B = (float)(-2.0 * 0.7978845608028654 * 1.4426950408889634 * 0.044715);
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * __builtin_fmaf(B, x * x, A)));
 }
 __device__ __forceinline__ float gelu_tanh_fast_f(float x) { return x * gelu_sigmoid_2u(x); }
 __device__ __forceinline__ float gelu_tanh_grad_fast_f(float x) {
@@ -163,6 +163,7 @@ struct spa3d_ctx {
                       // wins on every one of them (out-projection 33.0 -> 27.8 ms/step, MLP-out 49.3 -> 44.0, plain dX shapes +1.5 %): NT class -17 ms/step
   int nt_coarse = 1;  // persistent NT kernel with two phases per K-tile (32 MFMAs per barrier pair) instead of four (SPA3D_NT_COARSE)
   int nt_stream = 1;  // non-temporal stores for bf16 GEMM outputs >= 512 MB (SPA3D_NT_STREAM=0 disables)
+  int mlp_fused = 1;  // track-encoder MLP forward as ONE sequence-resident kernel (mlp_fused.hip); 0 = the two tiled GEMMs
   int nt_occ = 1;     // single-buffer 4-workgroups/CU NT kernel for K <= 512 (SPA3D_NT_OCC=0 disables)
   bool ln_folded = false;        // set by gemm_nt_bf16: the last call also produced GemmDesc::ln_out / ln_stats
   int ln_fold = 0;               // LayerNorm forward folded into the epilogue of the preceding N = 384 GEMM (SPA3D_LN_FOLD=1): bit-identical outputs, measured
@@ -233,6 +234,11 @@ template <typename T> void gemm_generic(spa3d_ctx* c, const GemmDesc& d);
 // tiled bf16 kernels (gemm_fast.hip).  Return false if the shape/layout is not supported.
 bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d);
 bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d);
+// sequence-resident MLP forward for d = 384, mlp = 1536 (mlp_fused.hip): y = a + MLP(na), h / hpre kept; false = shape not covered
+template <typename S> void mlp_fused_pack(spa3d_ctx* c, const S* w_in /*[384][1536]*/, const S* w_out /*[1536][384]*/, bf16_t* wpk);
+int64_t mlp_fused_pack_elems();
+bool mlp_fused_fwd(spa3d_ctx* c, const bf16_t* na, const bf16_t* a, bf16_t* y, bf16_t* h, bf16_t* hpre, int64_t M, int d, int mlp,
+                   const bf16_t* wpk, const float* b_in, const float* b_out);
 
 // ------------------------------------------------------------------------------------------
 // elementwise / reduction kernels (kernels.hip), all asynchronous on c->stream; no-ops when c->dry

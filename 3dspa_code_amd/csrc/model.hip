@@ -51,6 +51,7 @@ template <typename T> struct BlockW {
   const float *norm_q, *norm_attn, *sq, *sk, *csq = nullptr, *csk = nullptr;
   float *g_norm_q, *g_norm_attn, *g_sq, *g_sk, *g_csq = nullptr, *g_csk = nullptr;
   Lin<T> qkv, out, cq, ckv, cout, mlp_in, mlp_out;
+  T* mlp_pk = nullptr;  // both MLP kernels as the fused forward kernel's weight stream (mlp_fused.hip; d = 384, mlp = 1536, 16-bit modes)
 };
 template <typename T> struct XfW { std::vector<BlockW<T>> blocks; const float* norm_enc; float* g_norm_enc; int d; };
 template <typename T> struct BlockStash {
@@ -133,6 +134,12 @@ template <typename T> struct Net {
       }
       w.mlp_in = make_lin({b + "/MLP_in/kernel"}, b + "/MLP_in/bias", d, mlp);
       w.mlp_out = make_lin({b + "/MLP_out/kernel"}, b + "/MLP_out/bias", mlp, d);
+      if constexpr (sizeof(T) == 2) {
+        if (c->mlp_fused && !w.cross && d == 384 && mlp == 1536) {
+          w.mlp_pk = alloc<T>(mlp_fused_pack_elems());
+          mlp_fused_pack<float>(c, w.mlp_in.src[0], w.mlp_out.src[0], w.mlp_pk);
+        }
+      }
       x.blocks.push_back(w);
     }
     x.norm_enc = p(name + "/norm_encoder/scale"); x.g_norm_enc = gr(name + "/norm_encoder/scale");
@@ -274,8 +281,14 @@ template <typename T> struct Net {
     if (!na) { na = alloc<T>(Mg * d); st2 = alloc<float>(Mg * 2); }
     if (!ln2_folded) k_layernorm<T>(c, a, w.norm_attn, na, st2, M, d);                  // :103-105
     T* hpre = alloc<T>(Mg * w.mlp); T* h = alloc<T>(Mg * w.mlp);
-    lin_fwd(w.mlp_in, na, h, Mg, EPI_GELU, nullptr, 0, 0, 0, 0, 0, 0, hpre);             // :106  h = gelu(hpre), both kept for the backward
-    lin_fwd(w.mlp_out, h, y, Mg, EPI_NONE, a);                                           // :107-108
+    bool fused = false;
+    if constexpr (sizeof(T) == 2) {  // :103-108 as one sequence-resident kernel (track encoder widths): h is never read back from HBM
+      if (w.mlp_pk && c->gemm_impl != 1) fused = mlp_fused_fwd(c, na, a, y, h, hpre, Mg, d, w.mlp, w.mlp_pk, w.mlp_in.bias, w.mlp_out.bias);
+    }
+    if (!fused) {
+      lin_fwd(w.mlp_in, na, h, Mg, EPI_GELU, nullptr, 0, 0, 0, 0, 0, 0, hpre);           // :106  h = gelu(hpre), both kept for the backward
+      lin_fwd(w.mlp_out, h, y, Mg, EPI_NONE, a);                                         // :107-108
+    }
     if (st) { st->x = const_cast<T*>(sh ? sh->xU : x); st->nq = nq; st->qkv = qkv; st->o = o; st->a = a; st->na = na; st->hpre = hpre; st->h = h;
               st->st1 = st1; st->st2 = st2; st->cq = cq; st->ckv = ckv; st->co = co; st->lse = lse; st->clse = clse; st->shared = sh != nullptr; }
     else c->ar.release(mk);
@@ -910,6 +923,7 @@ int spa3d_create(const spa3d_config* cfg, spa3d_handle* out) {
   e = getenv("SPA3D_TN_ROUNDS"); if (e) c->tn_rounds = atoi(e);
   e = getenv("SPA3D_TN_SEG"); if (e) c->tn_seg = atoi(e);
   e = getenv("SPA3D_LN_FOLD"); if (e) c->ln_fold = atoi(e);
+  e = getenv("SPA3D_MLP_FUSED"); if (e) c->mlp_fused = atoi(e);
   *out = c;
   return SPA3D_OK;
 }
@@ -984,6 +998,7 @@ int spa3d_set_option(spa3d_handle h, const char* name, double value) {
   else if (n == "attn_bwd_mode") h->attn_bwd_mode = (int)value;
   else if (n == "attn_impl") h->attn_impl = (int)value;
   else if (n == "gemm_impl") h->gemm_impl = (int)value;
+  else if (n == "mlp_fused") h->mlp_fused = value != 0;
   else { h->err = "unknown option: " + n; return SPA3D_ERR_ARG; }
   return SPA3D_OK;
 }

@@ -91,6 +91,8 @@ int spa3d_op_linear_f16(const void* A, const void* B, const float* bias, const v
                         int32_t act, int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream);
 int spa3d_op_linear_bwd_f16(const void* A, const void* B, const void* dC, void* dA, float* dB, float* dbias, int64_t M, int32_t N, int32_t K,
                             int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream);
+int spa3d_op_mlp_fused_f16(const void* na, const void* a, const void* w_in, const float* b_in, const void* w_out, const float* b_out, void* y,
+                           void* h, void* hpre, int64_t M, int32_t d, int32_t mlp, int32_t dtype, void* ws, int64_t ws_bytes, void* stream);
 int spa3d_op_layernorm_f16(const void* x, const float* scale, void* y, float* stats, int64_t rows, int32_t d, int32_t dtype, void* stream);
 int spa3d_op_layernorm_bwd_f16(const void* x, const float* scale, const float* stats, const void* dy, void* dx, float* dscale, int64_t rows,
                                int32_t d, int32_t dtype, void* stream);
@@ -108,6 +110,7 @@ int spa3d_op_attention_bwd_f16(const void* q, const void* k, const void* v, int6
 #define spa3d_op_linear spa3d_op_linear_f16
 #define spa3d_op_linear_bwd spa3d_op_linear_bwd_f16
 #define spa3d_op_layernorm spa3d_op_layernorm_f16
+#define spa3d_op_mlp_fused spa3d_op_mlp_fused_f16
 #define spa3d_op_layernorm_bwd spa3d_op_layernorm_bwd_f16
 #define spa3d_op_attention spa3d_op_attention_f16
 #define spa3d_op_attention_bwd spa3d_op_attention_bwd_f16
@@ -142,6 +145,19 @@ int spa3d_op_linear_bwd(const void* A, const void* B, const void* dC, void* dA, 
   OpCtx c(stream, ws, ws_bytes);
   if (dtype == SPA3D_F32) return op_linear_bwd<float>(c, (const float*)A, (const float*)B, (const float*)dC, (float*)dA, dB, dbias, M, N, K, impl);
   return op_linear_bwd<bf16_t>(c, (const bf16_t*)A, (const bf16_t*)B, (const bf16_t*)dC, (bf16_t*)dA, dB, dbias, M, N, K, impl);
+}
+
+int spa3d_op_mlp_fused(const void* na, const void* a, const void* w_in, const float* b_in, const void* w_out, const float* b_out, void* y,
+                       void* h, void* hpre, int64_t M, int32_t d, int32_t mlp, int32_t dtype, void* ws, int64_t ws_bytes, void* stream) {
+  FWD16(spa3d_op_mlp_fused_f16(na, a, w_in, b_in, w_out, b_out, y, h, hpre, M, d, mlp, dtype, ws, ws_bytes, stream))
+  if (!na || !a || !w_in || !b_in || !w_out || !b_out || !y || !h || !hpre || dtype == SPA3D_F32) return SPA3D_ERR_ARG;
+  OpCtx c(stream, ws, ws_bytes);
+  bf16_t* wpk = c.alloc<bf16_t>(mlp_fused_pack_elems());
+  if (c.ar.overflow) return SPA3D_ERR_WORKSPACE;
+  if (d != 384 || mlp != 1536) return SPA3D_ERR_ARG;
+  mlp_fused_pack<bf16_t>(&c, (const bf16_t*)w_in, (const bf16_t*)w_out, wpk);
+  if (!mlp_fused_fwd(&c, (const bf16_t*)na, (const bf16_t*)a, (bf16_t*)y, (bf16_t*)h, (bf16_t*)hpre, M, d, mlp, wpk, b_in, b_out)) return SPA3D_ERR_ARG;
+  return c.status();
 }
 
 int spa3d_op_layernorm(const void* x, const float* scale, void* y, float* stats, int64_t rows, int32_t d, int32_t dtype, void* stream) {

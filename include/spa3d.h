@@ -199,6 +199,13 @@ int spa3d_op_linear_bwd(const void* A, const void* B, const void* dC, void* dA, 
                         int64_t M, int32_t N, int32_t K, int32_t dtype, int32_t impl,
                         void* ws, int64_t ws_bytes, void* stream);
 
+/* The MLP of ImprovedTransformerBlock (attention.py:103-108) as ONE sequence-resident kernel, 16-bit dtypes, d = 384 and mlp = 1536 only
+ * (the track encoder's widths; anything else returns SPA3D_ERR_ARG):  hpre = na @ w_in + b_in, h = tanh-gelu(hpre), y = a + h @ w_out + b_out.
+ * na, a, y [M,d]; h, hpre [M,mlp]; w_in [d,mlp], w_out [mlp,d] in `dtype`; biases f32.  ws >= 4 MiB. */
+int spa3d_op_mlp_fused(const void* na, const void* a, const void* w_in, const float* b_in, const void* w_out, const float* b_out,
+                       void* y, void* h, void* hpre, int64_t M, int32_t d, int32_t mlp, int32_t dtype,
+                       void* ws, int64_t ws_bytes, void* stream);
+
 /* y = LayerNorm(x)*scale (no bias, eps 1e-6, fast variance); stats[rows,2] = (mean, rstd) */
 int spa3d_op_layernorm(const void* x, const float* scale, void* y, float* stats, int64_t rows, int32_t d,
                        int32_t dtype, void* stream);
