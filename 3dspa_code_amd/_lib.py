@@ -62,9 +62,12 @@ _SIGS = {
     'spa3d_set_loss_scale_state': (C.c_int, [C.c_void_p, C.c_void_p]),
     'spa3d_grad_segments': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     'spa3d_set_grad_events': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'spa3d_grad_events_recorded': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    'spa3d_detach': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'spa3d_plan_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     'spa3d_prof_enable': (C.c_int, [C.c_void_p, C.c_int32]),
     'spa3d_prof_read': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
+    'spa3d_prof_dump': (C.c_int, [C.c_void_p, C.c_char_p]),
     'spa3d_uniform_noise': (C.c_int, [C.c_void_p, C.c_int64, C.c_uint32, C.c_uint32, C.c_void_p]),
     'spa3d_op_sin_embed': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     'spa3d_op_linear': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,

@@ -121,7 +121,7 @@ struct Arena {  // bump allocator over the caller's workspace; dry mode only cou
 
 // live per-kernel-class timing with HIP events on the launch stream (bench.py "roofline"; off by default)
 enum { PROF_GEMM_NT = 0, PROF_GEMM_TN = 1, PROF_GEMM_GENERIC = 2, PROF_ATTN_FWD = 3, PROF_ATTN_BWD = 4, PROF_LN_FWD = 5, PROF_LN_BWD = 6,
-       PROF_ATTN_Q1 = 7, PROF_NCLS = 8 };
+       PROF_ATTN_Q1 = 7, PROF_EMBED = 8, PROF_NCLS = 9 };  // PROF_EMBED brackets the whole input-embedding stage (its GEMMs are also in PROF_GEMM_NT)
 struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; int64_t tag[4] = {0, 0, 0, 0}; };  // tag: M, N, K, flags (GEMMs)
 struct Prof {
   bool on = false;
@@ -142,35 +142,49 @@ struct spa3d_ctx {
   Arena ar;
   bool dry = false;   // orchestration runs without launching (workspace sizing)
   int hip_err = 0;
-  int gemm_impl = 0;  // 0 auto, 1 generic only
-  int attn_impl = 0;
+  int gemm_impl = 0;  // 0 auto, 1 generic only, 2 tiled (see apply_gemm_impl)
+  int attn_impl = 0;  // 0 auto, 1 generic, 2 fused (see apply_attn_impl)
+  int chunk = 0;      // samples per chunk: 0 = as many as fit the workspace (spa3d_set_option "chunk")
   int ro_share = 1;       // readout block 1: LayerNorm / QKV once per distinct (sample, query frame) instead of per query (16-bit modes); SPA3D_RO_SHARE=0 disables
   int prune = 1;          // drop masked frame tokens from the track encoder (3DSPA model, fused 16-bit attention path); SPA3D_PRUNE=0 disables
   float loss_scale = 1.f;  // the 16-bit backward runs at loss x scale, parameter gradients are scaled back at the end: 1 = off (bf16 / fp32),
                            // > 0 a fixed scale, < 0 automatic with |loss_scale| the target head-gradient magnitude (fp16 mode: -16)
   void* grad_ev[2] = {nullptr, nullptr};  // spa3d_set_grad_events: recorded on the launch stream when a gradient segment is final (last chunk)
+  int64_t grad_ev_gen[2] = {0, 0};  // how many times each event has been recorded (spa3d_grad_events_recorded)
   bool last_chunk = false;
   const float* loss_scale_state = nullptr;  // caller-owned device float (spa3d_set_loss_scale_state): dynamic multiplier of the loss scale
   double plan_stats[4] = {0, 0, 0, 0};  // last train call: encoder rows kept, encoder rows dense, readout slots, queries (spa3d_plan_stats)
-  int attn_bwd_mode = 0;  // fused attention backward structure: 0 auto, 1 four images + concurrent roles, 2 split-pass 4 waves (2 WG/CU), 3 split-pass 8 waves
-  int nt_8p = 1;      // 8-phase kernels (256x256 / 128x384, counted vmcnt, staggered wave rows); 2 = also for small M, 0/3 = off
-  int tn_8p = 1;      // 8-phase TN (dW) kernels; SPA3D_TN_8P=0 disables, =2 forces (tests)
-  int tn_qp = 2;      // quarters (16 reduction rows) per phase of the 8-phase TN kernels: 2 = 16 MFMAs per barrier pair (+7-10 %), 1 = 8
-  int tn_seg = 1;     // dW of a fused q | k | v projection as ONE 8-phase TN GEMM with segmented outputs (SPA3D_TN_SEG=0: one GEMM per segment)
-  int tn_rounds = 0;  // 0: M-split count of the 8-phase TN kernels from the makespan model; > 0: 256 * rounds / tiles (experiments)
-  int nt_8pp = 5;     // persistent forms of the 8-phase NT kernels (SPA3D_NT_8PP=0 disables; 1 = the 256x256 one only: +3-6 %).  5 (default since round 3) = also the
-                      // persistent 128x384 kernel: rejected in round 2 on a plain-epilogue micro-benchmark, but IN THE STEP its shapes carry a residual operand and it
-                      // wins on every one of them (out-projection 33.0 -> 27.8 ms/step, MLP-out 49.3 -> 44.0, plain dX shapes +1.5 %): NT class -17 ms/step
-  int nt_coarse = 1;  // persistent NT kernel with two phases per K-tile (32 MFMAs per barrier pair) instead of four (SPA3D_NT_COARSE)
-  int nt_stream = 1;  // non-temporal stores for bf16 GEMM outputs >= 512 MB (SPA3D_NT_STREAM=0 disables)
-  int mlp_fused = 1;  // track-encoder MLP forward as ONE sequence-resident kernel (mlp_fused.hip); 0 = the two tiled GEMMs
-  int nt_occ = 1;     // single-buffer 4-workgroups/CU NT kernel for K <= 512 (SPA3D_NT_OCC=0 disables)
-  bool ln_folded = false;        // set by gemm_nt_bf16: the last call also produced GemmDesc::ln_out / ln_stats
-  int ln_fold = 0;               // LayerNorm forward folded into the epilogue of the preceding N = 384 GEMM (SPA3D_LN_FOLD=1): bit-identical outputs, measured
-                                 // net zero (LayerNorm class -10.5 ms/step, NT GEMM class +10-12), so off by default
+  // kernel-choice knobs behind gemm_impl / attn_impl (spa3d_set_option; values 3+ are test hooks that put small problems on the big kernels)
+  int attn_bwd_mode = 0;  // fused attention backward structure: 0 auto (1 up to S = 160, else 3), 1 four images + concurrent roles, 2 split-pass 4 waves, 3 split-pass 8 waves
+  int nt_8p = 1;          // 8-phase NT kernels (256x256 / 128x384): 1 for M >= 16 384, 2 for any M (tests), 0 off
+  int nt_8pp = 5;         // their persistent forms: 5 both tiles (default), 1 the 256x256 one only (tests: the non-persistent 128x384 kernel), 0 off
+  int tn_8p = 1;          // 8-phase TN (dW) kernels: 1 by size, 2 forced (tests), 0 off
+  int nt_occ = 1;         // single-buffer 4-workgroups/CU NT kernel for K <= 512; 0 (tests) = the double-buffered kernel
+  int nt_stream = 1;      // non-temporal stores for 16-bit outputs >= 512 MB
+  int embed_fused = 1;    // input embedding as ONE GEMM over the concatenated K written once, in compact row order (model.hip encode_chunk); gemm_impl 6 = the multi-pass path
+  int mlp_fused = 1;      // track-encoder MLP forward as ONE sequence-resident kernel (mlp_fused.hip); gemm_impl 6 = the two tiled GEMMs
+  int poison = 0;         // spa3d_set_option "poison": NaN-fill the workspace before every chunk and every op output before its launch (tests)
   bool tn_colsum_fused = false;  // set by gemm_tn_bf16: the last call also produced GemmDesc::colsum_out
   Prof prof;
 };
+
+// gemm_impl: 0 product dispatch | 1 generic kernels only | 2 tiled kernels, product tile choice (ops: error when unusable) -- and test hooks that put
+// SMALL problems on the big kernels: 3 every eligible GEMM on the 8-phase kernels (persistent forms included), 4 the same with the non-persistent
+// 128x384 kernel, 5 tiled without the single-buffer short-K kernel, 6 tiled GEMMs without the fused kernels (MLP forward as two GEMMs, multi-pass input embedding)
+inline void apply_gemm_impl(spa3d_ctx* c, int v) {
+  c->gemm_impl = v == 1 ? 1 : (v >= 2 ? 2 : 0);
+  c->nt_8p = 1; c->nt_8pp = 5; c->tn_8p = 1; c->nt_occ = 1; c->mlp_fused = 1; c->embed_fused = 1;
+  if (v == 3 || v == 4) { c->nt_8p = 2; c->tn_8p = 2; }
+  if (v == 4) c->nt_8pp = 1;
+  if (v == 5) c->nt_occ = 0;
+  if (v == 6) { c->mlp_fused = 0; c->embed_fused = 0; }
+}
+// attn_impl: 0 product dispatch | 1 generic composition (GEMMs + softmax kernels) | 2 fused kernels (ops: error when unusable) | 3 / 4 fused with the
+// split-pass backward on 4 / 8 waves also where the four-image kernel would run (S <= 160; tests)
+inline void apply_attn_impl(spa3d_ctx* c, int v) {
+  c->attn_impl = v == 1 ? 1 : (v >= 2 ? 2 : 0);
+  c->attn_bwd_mode = v == 3 ? 2 : (v == 4 ? 3 : 0);
+}
 
 struct ProfScope {  // records an event pair around the launches issued in its lifetime
   spa3d_ctx* c; ProfRec r; bool on;
@@ -220,10 +234,11 @@ struct GemmDesc {
   int32_t brow_group = 0, brow_skip = 0;  // same remap on B's k index (dW over token rows that skip the readout row)
   void* pre_out = nullptr;                // with EPI_GELU: the pre-activation (T, C layout) is stored here as well
   const void* zero_page = nullptr;        // >= 16 B of zeros (tiled TN kernel: rows past the end of the reduction)
-  // tiled NT with N == 384 (the 128 x 384-tile kernel owns whole rows): also emit LayerNorm(C) * ln_scale (no bias, eps 1e-6, fast variance; statistics
-  // of the 16-bit-rounded C, exactly what the stand-alone kernel would read back) and its (mean, rstd) rows; the callee reports it in
-  // spa3d_ctx::ln_folded, otherwise the caller runs k_layernorm itself
-  void* ln_out = nullptr; float* ln_stats = nullptr; const float* ln_scale = nullptr;
+  // one-pass input embedding (tiled NT, N == 384, 16-bit): K columns [0, K1) from A, [K1, K) from A2 (row stride sA2m); input rows gathered through
+  // arow_idx (both sources; also indexes r1_x), output rows scattered through crow_idx (< 0 = dropped); epilogue += r1_x[input row] * r1_w[n] in f32.
+  // gemm_nt_bf16 returns false when it cannot honour them (the caller then takes the multi-pass path)
+  const void* A2 = nullptr; int64_t sA2m = 0; int32_t K1 = 0; const int32_t* arow_idx = nullptr; const int32_t* crow_idx = nullptr;
+  const void* r1_x = nullptr; const float* r1_w = nullptr;
   int32_t seg_n = 0; void* C_seg[2] = {nullptr, nullptr};  // tiled TN (dW) only: output columns in seg_n-wide segments, segment s >= 1 in C_seg[s-1]
                                                           // (the q / k / v kernels of a fused projection are separate leaves); gemm_tn_bf16 returns
                                                           // false when it cannot honour it
@@ -268,6 +283,8 @@ template <typename T> void k_cast_to_f32(spa3d_ctx*, const T* src, float* dst, i
 template <typename T> void k_pack(spa3d_ctx*, const float* src, int64_t src_ld, int rows, int cols, T* dst_native, int64_t ldn, T* dst_T, int64_t ldt);
 template <typename T> void k_transpose(spa3d_ctx*, const T* src, int rows, int cols, T* dst);  // dst[c][r] = src[r][c]
 template <typename T> void k_set_readout_rows(spa3d_ctx*, T* tok, const float* readout, int64_t nseq, int S, int d);
+template <typename T> void k_embed_maps(spa3d_ctx*, const int32_t* row_src, int64_t rows, int S, int T_, int32_t* arow, int32_t* crow, T* tok, const float* readout, int d);
+void k_sum3(spa3d_ctx*, const float* a, const float* b, const float* c3, float* out, int n);
 void k_keymask(spa3d_ctx*, const float* visible, const int32_t* boundary, int64_t nseq, int N, int T_, float* km);
 template <typename T> void k_gather_rows(spa3d_ctx*, const T* src, int64_t src_stride_rows, T* dst, int64_t n, int d);
 // token pruning of the track encoder (kernels.hip): plan (returns the kept-row count, one stream sync) and rows-by-index movers

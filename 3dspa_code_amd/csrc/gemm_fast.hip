@@ -45,8 +45,11 @@ struct NtArgs {
 #ifdef SPA3D_ABLATE
   int ablate;
 #endif
+  // one-pass input embedding (non-persistent 128x384 8-phase kernel only; GemmDesc::A2 ...): K columns [0, K1) come from A, [K1, K) from A2 (row
+  // stride lda2); input rows are gathered through arow_idx (both sources), output rows scattered through crow_idx (< 0 = dropped); the
+  // epilogue adds the rank-1 term r1_x[input row] * r1_w[column] in f32
+  const bf16_t* A2; int64_t lda2; int K1; const int32_t* arow_idx; const int32_t* crow_idx; const bf16_t* r1_x; const float* r1_w;
   int nt_store;  // bf16 output with non-temporal stores: a streamed output far larger than the caches (+3-6 % measured at K = 384)
-  bf16_t* ln_out; float* ln_stats; const float* ln_scale;  // 128 x 384-tile kernel only (GemmDesc::ln_out)
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
@@ -438,7 +441,7 @@ __device__ __forceinline__ void nt_store4(const NtArgs& g, int64_t gm, int gn, c
 // (N = 384 in ONE tile: the A panel is read from HBM exactly once).  64 KiB per LDS buffer in both.
 // <4,2> = 128x128 on 80 KiB of LDS and <= 128 registers: TWO workgroups per CU, so one's epilogue (the store drain that is purely additive at
 // K = 384) can run under the other's K-loop -- the round-3 measurement of that hypothesis (SPA3D_NT_8P=42)
-template <int WMT, int WNT, bool COARSE = false>
+template <int WMT, int WNT, bool COARSE = false, bool EMB = false>  // EMB: the one-pass input-embedding operands of NtArgs are live
 __global__ __launch_bounds__(512, (WMT * WNT <= 8 ? 4 : 2)) void gemm_nt8p_kernel(NtArgs g) {
   constexpr int BM = 32 * WMT, BN = 64 * WNT;
   constexpr int NA = WMT / 4, NB = WNT / 2;   // LDS-DMA per thread per A / B half-tile
@@ -459,6 +462,7 @@ __global__ __launch_bounds__(512, (WMT * WNT <= 8 ? 4 : 2)) void gemm_nt8p_kerne
   const int sc = (scp ^ sr) * 8;
   // staging: 8-row group gi = 8i + w of a half-tile.  A-h: wave-row block gi / WMT, group gi % WMT; B-h: wave-column block gi / WNT
   const bf16_t* pa[2][NA]; const bf16_t* pb[2][NB];
+  const bf16_t* pa2[2][NA];  // second A source (columns K1 .. K), same rows
   int la[2][NA], lb[2][NB];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -466,7 +470,9 @@ __global__ __launch_bounds__(512, (WMT * WNT <= 8 ? 4 : 2)) void gemm_nt8p_kerne
     for (int i = 0; i < NA; ++i) {
       const int gi = i * 8 + w, ra = (gi / WMT) * (WMT * 16) + h * (WMT * 8) + (gi % WMT) * 8;
       int64_t am = m0 + ra + sr; if (am > g.M - 1) am = g.M - 1;
+      if (EMB && g.arow_idx) am = g.arow_idx[am];  // gathered input rows (the rows of a tile are the same for every K-tile: one lookup per lane)
       pa[h][i] = g.A + am * g.lda + sc; la[h][i] = ra * 128;
+      pa2[h][i] = (EMB && g.A2) ? g.A2 + am * g.lda2 + sc : nullptr;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -476,12 +482,16 @@ __global__ __launch_bounds__(512, (WMT * WNT <= 8 ? 4 : 2)) void gemm_nt8p_kerne
     }
   }
   const bool a_once = g.tiles_n == 1;  // the A panel is read by this workgroup only: stream it past L2
+  const int k1t = (EMB && g.A2) ? g.K1 / 64 : 0x7fffffff;  // K-tiles [0, k1t) from A, the rest from A2
   auto stageA = [&](int kt, int slot) {  // both halves of K-tile kt
     char* base = smem + slot * ASLOT;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int i = 0; i < NA; ++i) { if (a_once) GLDS16_NT(pa[h][i] + kt * 64, base + la[h][i]); else GLDS16(pa[h][i] + kt * 64, base + la[h][i]); }
+      for (int i = 0; i < NA; ++i) {
+        const bf16_t* src = (!EMB || kt < k1t) ? pa[h][i] + kt * 64 : pa2[h][i] + (kt - k1t) * 64;
+        if (a_once) GLDS16_NT(src, base + la[h][i]); else GLDS16(src, base + la[h][i]);
+      }
   };
   auto stageB = [&](int h, int kt) {
     char* base = smem + (kt & 1) * BBUF;
@@ -592,8 +602,8 @@ __global__ __launch_bounds__(512, (WMT * WNT <= 8 ? 4 : 2)) void gemm_nt8p_kerne
   constexpr int NIT = WMT * WNT / 4;
   // residual / pre-activation operand: ALL of the tile's loads go out before the first store (vmcnt retires in order: a load issued
   // after the first half's stores would be waited for together with their drain); 2 NIT x 4 VGPRs, the K-loop's fragments are dead
-  uint4 auxv[2][NIT];
-  if (g.aux) {
+  uint4 auxv[EMB ? 1 : 2][EMB ? 1 : NIT];  // (the embedding form has no aux operand: host)
+  if constexpr (!EMB) if (g.aux) {
 #pragma unroll
     for (int half = 0; half < 2; ++half)
 #pragma unroll
@@ -606,6 +616,23 @@ __global__ __launch_bounds__(512, (WMT * WNT <= 8 ? 4 : 2)) void gemm_nt8p_kerne
           int64_t crow = gm;
           if (g.crow_group > 0) crow = gm + (gm / g.crow_group + 1) * (int64_t)g.crow_skip;
           auxv[half][it] = *(const uint4*)(g.aux + crow * g.ldc + gn);
+        }
+      }
+  }
+  // embedding form: output row (scatter map) and the rank-1 operand's value per item, loaded before the first store like the aux operand
+  constexpr bool emb = EMB;
+  int crow_i[EMB ? 2 : 1][EMB ? NIT : 1]; float r1v[EMB ? 2 : 1][EMB ? NIT : 1];
+  if constexpr (EMB) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int id = it * 64 + lane, row = id / CPR;
+        const int64_t gm = m0 + wr * (WMT * 16) + half * (WMT * 8) + row;
+        crow_i[half][it] = -1; r1v[half][it] = 0.f;
+        if (gm < g.M) {
+          crow_i[half][it] = g.crow_idx ? g.crow_idx[gm] : (int)gm;
+          if (g.r1_x) r1v[half][it] = bf2f(g.r1_x[g.arow_idx ? g.arow_idx[gm] : gm]);
         }
       }
   }
@@ -622,96 +649,16 @@ __global__ __launch_bounds__(512, (WMT * WNT <= 8 ? 4 : 2)) void gemm_nt8p_kerne
     if (g.bias && gn < g.N) { const float4 b0 = *(const float4*)(g.bias + gn), b1 = *(const float4*)(g.bias + gn + 4);
       bv[it][0] = b0.x; bv[it][1] = b0.y; bv[it][2] = b0.z; bv[it][3] = b0.w; bv[it][4] = b1.x; bv[it][5] = b1.y; bv[it][6] = b1.z; bv[it][7] = b1.w; }
   }
-  if constexpr (WMT == 4 && WNT == 6) {
-    // ---- LayerNorm folded into this epilogue (the tile holds whole 384-wide rows; a row's columns sit in the four waves of a wave-row).
-    // Per half: (A) final values (bias, residual) -> C, and their 16-bit-rounded copies back into the wave's region; (B) lanes 0..31 sum
-    // their row's 96 values, partial (sum, sum of squares) into the wave's slack behind its region; workgroup barrier; (C) every lane
-    // combines the four partials of its row and writes LN(row) * scale; wave-column 0 writes (mean, rstd).  Host guarantees: N == 384,
-    // no GELU / f32 output / accumulate / row remap.  The scale vector is staged in LDS before the first store (a load issued behind the
-    // stores would wait for their drain: vmcnt retires in order).
-    if (g.ln_out) {
-      static_assert(EPI_STRIDE >= 12288 + 512 + 384, "slack for the LayerNorm partials and the scale slice");
-      float2* mypart = (float2*)(reg + 12288);          // [2 halves][32 rows]
-      float* mysc = (float*)(reg + 12288 + 512);        // this wave's 96 scale values
-      for (int t = lane; t < 96; t += 64) mysc[t] = g.ln_scale[wc * 96 + t];
+  float wv[EMB ? NBV : 1][8];  // rank-1 column weights
+  if constexpr (EMB)
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+  for (int it = 0; it < NBV; ++it) {
+    const int id = it * 64 + lane, c8 = id % CPR;
+    const int gn = n0 + wc * (WNT * 16) + c8 * 8;
 #pragma unroll
-        for (int i = 0; i < HM; ++i)
-#pragma unroll
-          for (int j = 0; j < WNT; ++j) *(f32x4*)(reg + (i * 16 + fr) * RB + (swz(j * 4 + fq, i * 16 + fr) << 4)) = acc[half * HM + i][j];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {  // (A)
-          const int id = it * 64 + lane, row = id / CPR, c8 = id - row * CPR;
-          f32x4* p0 = (f32x4*)(reg + row * RB + (swz(2 * c8, row) << 4)); f32x4* p1 = (f32x4*)(reg + row * RB + (swz(2 * c8 + 1, row) << 4));
-          const f32x4 v0 = *p0, v1 = *p1;
-          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          const int64_t gm = m0 + wr * (WMT * 16) + half * (WMT * 8) + row;
-          const int gn = wc * (WNT * 16) + c8 * 8;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = g.alpha * v[r] + bv[it][r];
-          if (g.aux) {
-            const unsigned* xp = (const unsigned*)&auxv[half][it];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { v[2 * r] += unpack_lo(xp[r]); v[2 * r + 1] += unpack_hi(xp[r]); }
-          }
-          uint4 o4; unsigned* op = (unsigned*)&o4;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) op[r] = (unsigned)f2bf(v[2 * r]) | ((unsigned)f2bf(v[2 * r + 1]) << 16);
-          if (gm < g.M) {
-            uint4* cp = (uint4*)((bf16_t*)g.C + gm * g.ldc + gn);
-            if (g.nt_store) { typedef __attribute__((ext_vector_type(4))) unsigned u32x4; __builtin_nontemporal_store(u32x4{o4.x, o4.y, o4.z, o4.w}, (u32x4*)cp); }
-            else *cp = o4;
-          }
-          *p0 = f32x4{unpack_lo(op[0]), unpack_hi(op[0]), unpack_lo(op[1]), unpack_hi(op[1])};   // what the stand-alone LayerNorm would read back
-          *p1 = f32x4{unpack_lo(op[2]), unpack_hi(op[2]), unpack_lo(op[3]), unpack_hi(op[3])};
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 32) {  // (B) row `lane` of this half: 24 chunks of 4 columns
-          float s_ = 0.f, ss_ = 0.f;
-#pragma unroll
-          for (int ch = 0; ch < 4 * WNT; ++ch) {
-            const f32x4 t = *(const f32x4*)(reg + lane * RB + (swz(ch, lane) << 4));
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s_ += t[r]; ss_ += t[r] * t[r]; }
-          }
-          mypart[half * 32 + lane] = float2{s_, ss_};
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {  // (C)
-          const int id = it * 64 + lane, row = id / CPR, c8 = id - row * CPR;
-          float s_ = 0.f, ss_ = 0.f;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float2 pj = ((const float2*)(smem + (wr * 4 + j) * EPI_STRIDE + 12288))[half * 32 + row];
-            s_ += pj.x; ss_ += pj.y;
-          }
-          const float mu = s_ * (1.f / 384.f);
-          const float var = fmaxf(ss_ * (1.f / 384.f) - mu * mu, 0.f);
-          const float rs = rsqrtf(var + 1e-6f);
-          const f32x4 v0 = *(const f32x4*)(reg + row * RB + (swz(2 * c8, row) << 4));
-          const f32x4 v1 = *(const f32x4*)(reg + row * RB + (swz(2 * c8 + 1, row) << 4));
-          const f32x4 s0 = *(const f32x4*)(mysc + c8 * 8), s1 = *(const f32x4*)(mysc + c8 * 8 + 4);
-          const int64_t gm = m0 + wr * (WMT * 16) + half * (WMT * 8) + row;
-          const int gn = wc * (WNT * 16) + c8 * 8;
-          uint4 o4; unsigned* op = (unsigned*)&o4;
-          op[0] = (unsigned)f2bf((v0[0] - mu) * rs * s0[0]) | ((unsigned)f2bf((v0[1] - mu) * rs * s0[1]) << 16);
-          op[1] = (unsigned)f2bf((v0[2] - mu) * rs * s0[2]) | ((unsigned)f2bf((v0[3] - mu) * rs * s0[3]) << 16);
-          op[2] = (unsigned)f2bf((v1[0] - mu) * rs * s1[0]) | ((unsigned)f2bf((v1[1] - mu) * rs * s1[1]) << 16);
-          op[3] = (unsigned)f2bf((v1[2] - mu) * rs * s1[2]) | ((unsigned)f2bf((v1[3] - mu) * rs * s1[3]) << 16);
-          if (gm < g.M) {
-            uint4* yp = (uint4*)(g.ln_out + gm * 384 + gn);
-            if (g.nt_store) { typedef __attribute__((ext_vector_type(4))) unsigned u32x4; __builtin_nontemporal_store(u32x4{o4.x, o4.y, o4.z, o4.w}, (u32x4*)yp); }
-            else *yp = o4;
-            if (wc == 0 && c8 == 0) *(float2*)(g.ln_stats + gm * 2) = float2{mu, rs};
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      return;
-    }
+    for (int r = 0; r < 8; ++r) wv[it][r] = 0.f;
+    if (g.r1_x && gn < g.N) { const float4 b0 = *(const float4*)(g.r1_w + gn), b1 = *(const float4*)(g.r1_w + gn + 4);
+      wv[it][0] = b0.x; wv[it][1] = b0.y; wv[it][2] = b0.z; wv[it][3] = b0.w; wv[it][4] = b1.x; wv[it][5] = b1.y; wv[it][6] = b1.z; wv[it][7] = b1.w; }
   }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -728,20 +675,32 @@ __global__ __launch_bounds__(512, (WMT * WNT <= 8 ? 4 : 2)) void gemm_nt8p_kerne
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       const int64_t gm = m0 + wr * (WMT * 16) + half * (WMT * 8) + row;
       const int gn = n0 + wc * (WNT * 16) + c8 * 8;
-      if (gm < g.M && gn < g.N) nt_store8<true>(g, gm, gn, v, bv[CONSTC ? 0 : it], auxv[half][it]);
+      if constexpr (EMB) {  // y = acc + bias + x_row * w_col (all f32), rounded once, into the mapped row
+        if (crow_i[half][it] >= 0 && gn < g.N) {
+          const float xr = r1v[half][it];
+          uint4 o4; unsigned* op = (unsigned*)&o4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float y0 = (g.alpha * v[2 * r] + bv[CONSTC ? 0 : it][2 * r]) + xr * wv[CONSTC ? 0 : it][2 * r];
+            const float y1 = (g.alpha * v[2 * r + 1] + bv[CONSTC ? 0 : it][2 * r + 1]) + xr * wv[CONSTC ? 0 : it][2 * r + 1];
+            op[r] = (unsigned)f2bf(y0) | ((unsigned)f2bf(y1) << 16);
+          }
+          *(uint4*)((bf16_t*)g.C + (int64_t)crow_i[half][it] * g.ldc + gn) = o4;
+        }
+      } else if (gm < g.M && gn < g.N) nt_store8<true>(g, gm, gn, v, bv[CONSTC ? 0 : it], auxv[half][it]);
     }
     __builtin_amdgcn_wave_barrier();
   }
 }
 
-template <int WMT, int WNT>
+template <int WMT, int WNT, bool EMB = false>
 static void launch_nt8p(spa3d_ctx* c, const NtArgs& g) {
   NtArgs g2 = g; g2.tiles_m = (int)((g.M + 32 * WMT - 1) / (32 * WMT)); g2.tiles_n = g.N / (64 * WNT);
   const int64_t b2 = (int64_t)((g2.tiles_m + 7) / 8) * 8 * g2.tiles_n;
   static bool attr = false;
   constexpr int LDS = (3 * 32 * WMT + 2 * 64 * WNT) * 128;  // 160 KiB <8,4>, 144 KiB <4,6>
-  if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<WMT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
-  gemm_nt8p_kernel<WMT, WNT><<<(unsigned)b2, 512, LDS, c->stream>>>(g2);
+  if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<WMT, WNT, false, EMB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  gemm_nt8p_kernel<WMT, WNT, false, EMB><<<(unsigned)b2, 512, LDS, c->stream>>>(g2);
 }
 
 // =================================================================================================================
@@ -1035,8 +994,13 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   g.bias = d.bias; g.aux = (const bf16_t*)d.aux; g.pre_out = (bf16_t*)d.pre_out; g.epi = d.epi; g.out_f32 = d.out_f32; g.accumulate = d.accumulate; g.alpha = d.alpha;
   g.tiles_m = (int)((d.M + 127) / 128); g.tiles_n = (d.N + 127) / 128;
   g.crow_group = d.crow_group; g.crow_skip = d.crow_skip;
-  g.ln_out = nullptr; g.ln_stats = nullptr; g.ln_scale = nullptr;
-  c->ln_folded = false;
+  g.A2 = (const bf16_t*)d.A2; g.lda2 = d.sA2m; g.K1 = d.K1; g.arow_idx = d.arow_idx; g.crow_idx = d.crow_idx; g.r1_x = (const bf16_t*)d.r1_x; g.r1_w = d.r1_w;
+  const bool emb = d.A2 || d.arow_idx || d.crow_idx || d.r1_x;
+  if (emb) {  // one-pass input embedding: only the non-persistent 128 x 384 8-phase kernel carries these operands
+    if (d.N != 384 || d.out_f32 || d.accumulate || d.aux || d.pre_out || d.epi != EPI_NONE || d.crow_group) return false;
+    if (d.A2 && (d.K1 % 64 || d.K1 <= 0 || d.K1 >= d.K || d.sA2m % 8 || !aligned16(d.A2))) return false;
+    if (d.r1_x && !d.r1_w) return false;
+  }
 #ifdef SPA3D_ABLATE
   { const char* e = getenv("SPA3D_ABLATE"); g.ablate = e ? atoi(e) : 0; }
 #endif
@@ -1050,48 +1014,34 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
                ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N * (d.out_f32 ? 2.0 : 1.0) * (d.accumulate ? 2.0 : 1.0) + (double)d.M * d.N * ((d.aux ? 1.0 : 0.0) + (d.pre_out ? 1.0 : 0.0))) * 2.0);
   ps.tag(d.M, d.N, d.K, d.epi | (d.aux ? 4 : 0) | (d.pre_out ? 8 : 0) | (d.out_f32 ? 16 : 0) | (d.accumulate ? 32 : 0) | (d.crow_group ? 64 : 0) | (d.sAm != d.K ? 128 : 0));
   const int KT = d.K / 64;
-  // 8-phase kernels: 256x256 when 256 | N, 128x384 when 384 | N (see the kernel header for the measurements)
-  if (c->nt_8p && (d.N % 256 == 0 || d.N % 384 == 0 || (c->nt_8p == 42 && d.N % 128 == 0)) && (d.M >= 256 * 64 || c->nt_8p == 2 || c->nt_8p == 42) && c->nt_8p != 3) {
-    const bool pers_ok = c->nt_8pp && c->nt_8p != 44 && c->nt_8p != 42 && d.K >= 128 && !d.accumulate && d.crow_group == 0 && d.M % 8 == 0 &&
-                         (!d.aux || (c->nt_8pp != 3 && !d.pre_out && !d.out_f32));
-    static const int pref384 = [] { const char* e = getenv("SPA3D_NT_PREF384"); return e ? atoi(e) : 0; }();  // experiment: K <= pref384 and 384 | N -> the persistent 128x384 kernel
-    const bool use384 = pers_ok && c->nt_8pp == 5 && !d.pre_out && !d.out_f32 && d.N % 384 == 0 && (d.N % 256 != 0 || d.K <= pref384);
-    if (pers_ok && d.N % 256 == 0 && !use384) {  // persistent 256x256 (accumulate would add loads to the counted wait)
+  if (emb) { g.nt_store = 0; launch_nt8p<4, 6, true>(c, g); SPA_LAUNCH_CHECK(c); return true; }
+  // 8-phase kernels: 256x256 when 256 | N, 128x384 when 384 | N (see the kernel header for the measurements); nt_8p == 2 (tests): any M
+  if (c->nt_8p && (d.N % 256 == 0 || d.N % 384 == 0) && (d.M >= 256 * 64 || c->nt_8p == 2)) {
+    // persistent forms (nt_8pp; accumulate would add loads to the counted wait).  nt_8pp == 1 (tests): the 256x256 one only
+    const bool pers_ok = c->nt_8pp && d.K >= 128 && !d.accumulate && d.crow_group == 0 && d.M % 8 == 0 && (!d.aux || (!d.pre_out && !d.out_f32));
+    const bool use384 = pers_ok && c->nt_8pp == 5 && !d.pre_out && !d.out_f32 && d.N % 384 == 0 && d.N % 256 != 0;
+    if (pers_ok && d.N % 256 == 0) {
       NtArgs g2 = g; g2.tiles_m = (int)((g.M + 255) / 256); g2.tiles_n = g.N / 256;
       static bool attrp = false;
       if (!attrp) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<8, 4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<8, 4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<8, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         attrp = true;
       }
       if (d.aux) gemm_nt8pp_kernel<8, 4, true, true><<<256, 512, 163840, c->stream>>>(g2);
-      else if (c->nt_coarse) gemm_nt8pp_kernel<8, 4, true, false><<<256, 512, 163840, c->stream>>>(g2);
-      else gemm_nt8pp_kernel<8, 4, false, false><<<256, 512, 163840, c->stream>>>(g2);
-    } else if (use384) {  // persistent 128x384 (SPA3D_NT_8PP=5, the default since round 3): slower than the non-persistent kernel on a PLAIN epilogue at K = 768 (759 vs 840 TF/s: 96-B row segments from the half-width epilogue passes), faster on every N = 384 shape of the step, whose epilogues mostly carry a residual (out-projection +19 %, MLP-out +12 %, dX shapes +1.5 %)
+      else gemm_nt8pp_kernel<8, 4, true, false><<<256, 512, 163840, c->stream>>>(g2);
+    } else if (use384) {  // persistent 128x384: slower than the non-persistent kernel on a PLAIN epilogue at K = 768 (759 vs 840 TF/s), faster on every N = 384 shape of the step, whose epilogues mostly carry a residual (out-projection +19 %, MLP-out +12 %, dX shapes +1.5 %)
       NtArgs g2 = g; g2.tiles_m = (int)((g.M + 127) / 128); g2.tiles_n = g.N / 384;
       static bool attrq = false;
       if (!attrq) {
         (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<4, 6, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<4, 6, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<4, 6, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        (void)hipFuncSetAttribute((const void*)gemm_nt8pp_kernel<4, 6, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         attrq = true;
       }
-      static const int coarse384 = [] { const char* e = getenv("SPA3D_NT_COARSE384"); return e ? atoi(e) : 0; }();  // experiment: two-phase K-tiles in the persistent 128x384 kernel
-      if (coarse384) { if (d.aux) gemm_nt8pp_kernel<4, 6, true, true><<<256, 512, 163840, c->stream>>>(g2); else gemm_nt8pp_kernel<4, 6, true, false><<<256, 512, 163840, c->stream>>>(g2); }
-      else if (d.aux) gemm_nt8pp_kernel<4, 6, false, true><<<256, 512, 163840, c->stream>>>(g2);
+      if (d.aux) gemm_nt8pp_kernel<4, 6, false, true><<<256, 512, 163840, c->stream>>>(g2);
       else gemm_nt8pp_kernel<4, 6, false, false><<<256, 512, 163840, c->stream>>>(g2);
-    } else if (c->nt_8p == 42 && d.N % 128 == 0) launch_nt8p<4, 2>(c, g);
-    else if (d.N % 256 == 0) { if (c->nt_8p == 44) launch_nt8p<4, 4>(c, g); else launch_nt8p<8, 4>(c, g); }
-    else {
-      // LayerNorm of the output folded into the epilogue: whole rows in one tile, plain epilogue (bias / residual only)
-      if (d.ln_out && c->ln_fold && d.N == 384 && d.sCm == 384 && d.epi == EPI_NONE && !d.out_f32 && !d.accumulate && d.crow_group == 0 && !d.pre_out &&
-          d.alpha == 1.f && d.ln_stats && d.ln_scale && aligned16(d.ln_out)) {
-        g.ln_out = (bf16_t*)d.ln_out; g.ln_stats = d.ln_stats; g.ln_scale = d.ln_scale; c->ln_folded = true;
-      }
-      launch_nt8p<4, 6>(c, g);
-    }
+    } else if (d.N % 256 == 0) launch_nt8p<8, 4>(c, g);
+    else launch_nt8p<4, 6>(c, g);
     SPA_LAUNCH_CHECK(c);
     return true;
   }
@@ -1470,7 +1420,7 @@ static void launch_tn8p_q(spa3d_ctx* c, TnArgs g, int rounds) {
 
 template <int WIT, int WNT>
 static void launch_tn8p(spa3d_ctx* c, const TnArgs& g, int rounds) {
-  if (c->tn_qp == 2) launch_tn8p_q<WIT, WNT, 2>(c, g, rounds); else launch_tn8p_q<WIT, WNT, 1>(c, g, rounds);
+  launch_tn8p_q<WIT, WNT, 2>(c, g, rounds);  // two quarters per phase (+7-10 % over one: DESIGN.md 4, item 5)
 }
 
 bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d) {
@@ -1497,7 +1447,7 @@ bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d) {
     if (wb <= 1.25 || c->tn_8p == 2) {
       ProfScope ps(c, PROF_GEMM_TN, 2.0 * (double)M * Ki * N, ((double)M * Ki + (double)M * N) * 2.0);
       ps.tag(M, N, Ki, 0);
-      const int rounds = c->tn_rounds;
+      const int rounds = 0;  // M-split count from the makespan model
       g.colsum = d.colsum_out; c->tn_colsum_fused = d.colsum_out != nullptr;
       if (w0 <= wb * 1.0001) launch_tn8p<4, 2>(c, g, rounds);
       else if (w1 <= wb * 1.0001) launch_tn8p<2, 3>(c, g, rounds);

@@ -833,6 +833,34 @@ template <typename T> void k_set_readout_rows(spa3d_ctx* c, T* tok, const float*
   if (c->dry || nseq == 0) return;
   set_readout_kernel<T><<<GRID1D(nseq * d, 256), 256, 0, c->stream>>>(tok, readout, nseq, S, d); SPA_LAUNCH_CHECK(c);
 }
+// One-pass embedding (model.hip encode_chunk): row maps of the token rows the encoder keeps.  Row j of the (compact or dense) token buffer is dense
+// token q = row_src[j] (or j) = (seq, s): a frame token (s >= 1) reads input row seq * T + s - 1 and is written to row j; the readout token (s == 0)
+// has no input -- its GEMM row is dropped (crow = -1, arow = any valid row) and row j receives the readout parameter here (3d:161-165).
+template <typename T>
+__global__ void embed_maps_kernel(const int32_t* __restrict__ row_src, int64_t rows, int S, int T_, int32_t* __restrict__ arow, int32_t* __restrict__ crow,
+                                  T* __restrict__ tok, const float* __restrict__ ro, int d) {
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < rows; j += (int64_t)gridDim.x * 256) {
+    const int64_t q = row_src ? row_src[j] : j;
+    const int64_t seq = q / S; const int s_ = (int)(q - seq * S);
+    if (s_ == 0) {
+      arow[j] = (int32_t)(seq * T_); crow[j] = -1;
+      for (int k = 0; k < d; ++k) st(tok + j * d + k, ro[k]);
+    } else { arow[j] = (int32_t)(seq * T_ + s_ - 1); crow[j] = (int32_t)j; }
+  }
+}
+template <typename T>
+void k_embed_maps(spa3d_ctx* c, const int32_t* row_src, int64_t rows, int S, int T_, int32_t* arow, int32_t* crow, T* tok, const float* readout, int d) {
+  if (c->dry || rows == 0) return;
+  embed_maps_kernel<T><<<GRID1D(rows, 256), 256, 0, c->stream>>>(row_src, rows, S, T_, arow, crow, tok, readout, d); SPA_LAUNCH_CHECK(c);
+}
+__global__ void sum3_kernel(const float* a, const float* b, const float* c3, float* out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (a ? a[i] : 0.f) + (b ? b[i] : 0.f) + (c3 ? c3[i] : 0.f);
+}
+void k_sum3(spa3d_ctx* c, const float* a, const float* b, const float* c3, float* out, int n) {
+  if (c->dry) return;
+  sum3_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(a, b, c3, out, n); SPA_LAUNCH_CHECK(c);
+}
 // key mask (repairs R2/R3): km[seq][0]=1 ; km[seq][1+t] = visible[seq][t]!=0 && t < boundary[b]
 __global__ void keymask_kernel(const float* __restrict__ vis, const int32_t* __restrict__ boundary, int64_t nseq, int N, int T_, float* km) {
   const int S = T_ + 1;
@@ -1473,6 +1501,24 @@ void k_assemble_readout_bwd(spa3d_ctx* c, const T* dseq, const int32_t* qframe, 
 // head[q][c*T+t], c<3 coords (coordinate-major), c==3 visibility logit
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float log_sigmoid_f(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
+// The loss numerators and the visible count are summed over the whole batch by thousands of workgroups.  Float atomics make that sum depend
+// on arrival order (the same batch gave 14089.21875 and 14089.216796875 in round 3), so two data-parallel replicas could log different
+// losses and a test could not ask for bit-equal reruns.  Each workgroup reduces in a fixed order and adds its partial as a 64-bit FIXED-POINT
+// integer (2^-24 units: exact, order-independent integer addition; quantisation 6e-8 per workgroup, far below fp32 resolution of the sums).
+// Layout of the 8-float `sums` block: three 64-bit accumulators {position numerator, bce numerator, visible count} | denominator | loss scale.
+// A partial that is not finite or beyond the fixed-point range poisons its accumulator (top bit pattern LOSS_POISON -> the sum reads as NaN).
+constexpr float LOSS_FIX = 16777216.f;                 // 2^24
+constexpr long long LOSS_POISON = 0x4000000000000000ll;  // > any legitimate sum: 4096 workgroups x 2^50
+__device__ __forceinline__ void loss_acc_add(unsigned long long* acc, float partial) {
+  const float f = partial * LOSS_FIX;
+  long long q = (fabsf(f) < 1.0e15f) ? __float2ll_rn(f) : LOSS_POISON;   // NaN fails the comparison too
+  atomicAdd(acc, (unsigned long long)q);
+}
+__device__ __forceinline__ float loss_acc_read(const unsigned long long* acc) {
+  const long long q = (long long)*acc;
+  if (q >= LOSS_POISON / 2 || q <= -LOSS_POISON / 2) return __int_as_float(0x7fc00000);
+  return (float)((double)q * (1.0 / 16777216.0));
+}
 __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const float* __restrict__ head, int64_t nq, int T_, const float* __restrict__ tgt,
                                                             const float* __restrict__ tvis, float* __restrict__ tracks,
                                                             float* __restrict__ vlog, float* __restrict__ clog, float* __restrict__ sums, int NC) {
@@ -1504,8 +1550,8 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const float* __restr
   if ((threadIdx.x & 63) == 0) { red[0][w] = pn; red[1][w] = bn; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(sums + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-    atomicAdd(sums + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    loss_acc_add((unsigned long long*)sums + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    loss_acc_add((unsigned long long*)sums + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
   }
 }
 void k_loss_fwd(spa3d_ctx* c, const float* head, int64_t nq, int T_, const float* tgt, const float* tvis, float* tracks, float* vlog,
@@ -1532,8 +1578,8 @@ __global__ __launch_bounds__(256) void loss_from_preds_kernel(const float* __res
   if ((threadIdx.x & 63) == 0) { red[0][w] = pn; red[1][w] = bn; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(sums + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-    atomicAdd(sums + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    loss_acc_add((unsigned long long*)sums + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    loss_acc_add((unsigned long long*)sums + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
   }
 }
 void k_loss_from_preds(spa3d_ctx* c, const float* tracks, const float* vlog, int64_t n, const float* tgt, const float* tvis, float* sums,
@@ -1550,16 +1596,16 @@ __global__ __launch_bounds__(256) void vis_count_kernel(const float* __restrict_
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) loss_acc_add((unsigned long long*)out, red[0] + red[1] + red[2] + red[3]);
 }
 void k_vis_count(spa3d_ctx* c, const float* tvis, int64_t n, float* out) {
   if (c->dry || n == 0) return;
   unsigned g = (unsigned)std::min<int64_t>(cdiv(n, 256), 1024);
   vis_count_kernel<<<g, 256, 0, c->stream>>>(tvis, n, out); SPA_LAUNCH_CHECK(c);
 }
-// sums = {pos_num, bce_num, vis_cnt}; denom_dev = denom_host>0 ? denom_host : max(vis_cnt,1)
+// sums = {pos_num, bce_num, vis_cnt} (fixed-point accumulators, see loss_acc_add); denom_dev = denom_host>0 ? denom_host : max(vis_cnt,1)
 __global__ void set_denom_kernel(const float* sums, float denom_host, float* denom_dev) {
-  *denom_dev = denom_host > 0.f ? denom_host : fmaxf(sums[2], 1.f);
+  *denom_dev = denom_host > 0.f ? denom_host : fmaxf(loss_acc_read((const unsigned long long*)sums + 2), 1.f);
 }
 void k_set_denom(spa3d_ctx* c, const float* sums, float denom_host, float* denom_dev) {
   if (c->dry) return;
@@ -1567,7 +1613,7 @@ void k_set_denom(spa3d_ctx* c, const float* sums, float denom_host, float* denom
 }
 __global__ void loss_finalize_kernel(const float* sums, const float* denom_dev, float l1w, float bcew, float* loss3) {
   float d = *denom_dev;
-  float pos = sums[0] / d, vis = sums[1] / d;
+  float pos = loss_acc_read((const unsigned long long*)sums + 0) / d, vis = loss_acc_read((const unsigned long long*)sums + 1) / d;
   loss3[0] = l1w * pos + bcew * vis; loss3[1] = pos; loss3[2] = vis;
 }
 void k_loss_finalize(spa3d_ctx* c, const float* sums, const float* denom_dev, float l1w, float bcew, float* loss3) {
@@ -1632,18 +1678,26 @@ void k_unscale(spa3d_ctx* c, float* a, const float* scale_dev, int64_t n) {
 // ---------------------------------------------------------------------------------------------
 // optimizer: clip_by_global_norm -> adamw -> apply_updates on flat buffers (train.py:239-242)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* out) {
+// Global gradient norm, reproducible: every workgroup writes ITS partial sum of squares to scratch[SUMSQ_OFF + block] (fixed thread -> element
+// map, fixed reduction tree) and adamw_guard_kernel adds the partials in index order.  A float atomicAdd here made the clip factor -- and so the
+// whole AdamW update -- depend on arrival order: two data-parallel replicas holding bit-identical reduced gradients could drift apart.
+constexpr int SUMSQ_MAXB = 512, SUMSQ_OFF = 256;  // partials live in floats [256, 768) of the >= 4 KiB scratch block
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* partial) {
   __shared__ float red[4];
   float s = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += g[i] * g[i];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, int64_t n, float lr, float bc1, float bc2, float clip, float b1,
+                                                    float* __restrict__ v, int64_t n, float lr, float tstep, float clip, float b1,
                                                     float b2, float eps, float wd, float* scratch) {
+  // bias correction at the number of updates actually APPLIED: calls so far (tstep = step + 1) minus the steps skipped before this one
+  // (scratch[3]; this kernel returns early when this step itself is skipped).  -expm1(t log b) keeps 1 - b^t accurate for b -> 1.
+  const float teff = fmaxf(tstep - scratch[3], 1.f);
+  const float bc1 = -expm1f(teff * logf(b1)), bc2 = -expm1f(teff * logf(b2));
   const float gn = sqrtf(scratch[1]);
   const float sc = gn < clip ? 1.f : clip / gn;
   if (blockIdx.x == 0 && threadIdx.x == 0) scratch[0] = gn;
@@ -1661,10 +1715,20 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 // scratch[2] := 1 if this step was skipped (non-finite gradient norm) else 0; scratch[3] += skipped steps; scratch[4] = dynamic loss-scale
 // multiplier (0 = 1; halved on a skip, doubled up to 1 after 200 finite steps counted in scratch[5]) -- read by set_loss_scale_kernel when the
 // caller registered it with spa3d_set_loss_scale_state.
-__global__ void adamw_guard_kernel(float* scratch) {
+__global__ __launch_bounds__(256) void adamw_guard_kernel(float* scratch, int nblocks) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += scratch[SUMSQ_OFF + i];  // fixed order: thread t takes partials t, t + 256
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x != 0) return;
+  scratch[1] = red[0];
   const bool bad = !(sqrtf(scratch[1]) <= 3.0e38f);
   scratch[2] = bad ? 1.f : 0.f;
-  float m = scratch[4]; if (!(m > 0.f && m <= 1.f)) m = 1.f;
+  // the dynamic loss-scale multiplier must be a power of two in [2^-24, 1]; anything else (uninitialised scratch of a caller written against
+  // the old contract, a stray value in (0,1]) reads as 1
+  float m = scratch[4]; { int e; if (!(m >= 5.9604645e-8f && m <= 1.f && frexpf(m, &e) == 0.5f)) m = 1.f; }
   if (bad) { scratch[3] += 1.f; m = fmaxf(m * 0.5f, 5.9604645e-8f); scratch[5] = 0.f; }
   else if (m < 1.f) { scratch[5] += 1.f; if (scratch[5] >= 200.f) { m = fminf(2.f * m, 1.f); scratch[5] = 0.f; } }
   scratch[4] = m;
@@ -1673,11 +1737,10 @@ void k_adamw(spa3d_ctx* c, float* p, const float* g, float* m, float* v, int64_t
              float eps, float wd, float* scratch) {
   (void)hipMemsetAsync(scratch, 0, 12, c->stream);
   unsigned gr = (unsigned)std::min<int64_t>(cdiv(n, 256), 4096);
-  sumsq_kernel<<<gr, 256, 0, c->stream>>>(g, n, scratch + 1);
-  adamw_guard_kernel<<<1, 1, 0, c->stream>>>(scratch);
-  double t = (double)(step + 1);
-  float bc1 = (float)(1.0 - pow((double)b1, t)), bc2 = (float)(1.0 - pow((double)b2, t));
-  adamw_kernel<<<gr, 256, 0, c->stream>>>(p, g, m, v, n, lr, bc1, bc2, clip, b1, b2, eps, wd, scratch);
+  const unsigned gs = (unsigned)std::min<int64_t>(cdiv(n, 256), SUMSQ_MAXB);
+  sumsq_kernel<<<gs, 256, 0, c->stream>>>(g, n, scratch + SUMSQ_OFF);
+  adamw_guard_kernel<<<1, 256, 0, c->stream>>>(scratch, (int)gs);
+  adamw_kernel<<<gr, 256, 0, c->stream>>>(p, g, m, v, n, lr, (float)(step + 1), clip, b1, b2, eps, wd, scratch);
   SPA_LAUNCH_CHECK(c);
 }
 
@@ -1731,6 +1794,7 @@ void k_uniform_noise(spa3d_ctx* c, float* out, int64_t n, uint32_t k0, uint32_t 
   template void k_pack<T>(spa3d_ctx*, const float*, int64_t, int, int, T*, int64_t, T*, int64_t);                                      \
   template void k_transpose<T>(spa3d_ctx*, const T*, int, int, T*);                                                                    \
   template void k_set_readout_rows<T>(spa3d_ctx*, T*, const float*, int64_t, int, int);                                                \
+  template void k_embed_maps<T>(spa3d_ctx*, const int32_t*, int64_t, int, int, int32_t*, int32_t*, T*, const float*, int);            \
   template void k_gather_rows<T>(spa3d_ctx*, const T*, int64_t, T*, int64_t, int);                                                     \
   template void k_rows_idx<T>(spa3d_ctx*, int, const T*, const int32_t*, T*, int64_t, int);                                                     \
   template void k_scatter_rows<T>(spa3d_ctx*, const T*, T*, int64_t, int64_t, int);                                                    \

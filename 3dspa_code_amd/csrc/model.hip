@@ -82,6 +82,7 @@ template <typename T> struct Net {
   std::map<std::string, int64_t> off;
   int H, Dh, E, NC; bool twoD;
   Lin<T> tok, dino, depth, comp, decomp, qenc, pred;
+  T* emb_wt = nullptr; float* emb_bias = nullptr; int emb_K = 0;  // one-pass embedding: [d][K_sin + K_dino] weights (K contiguous) and b_tok + b_dino + b_depth
   XfW<T> enc, t2l, dec, ro;
   const float *lat0, *readout; float *g_lat0, *g_readout;
   void* zero_page = nullptr;
@@ -155,6 +156,15 @@ template <typename T> struct Net {
     tok = make_lin({"track_token_projection/kernel"}, "track_token_projection/bias", (NC + 1) * 2 * nf, d);
     if (g.dino_feature_dim > 0) dino = make_lin({"dino_projection/kernel"}, "dino_projection/bias", g.dino_feature_dim, d);
     if (g.depth_feature_dim > 0) depth = make_lin({"depth_projection/kernel"}, "depth_projection/bias", g.depth_feature_dim, d);
+    if constexpr (sizeof(T) == 2) {
+      if (c->embed_fused && !twoD && d == 384 && tok.K % 64 == 0 && (g.dino_feature_dim == 0 || g.dino_feature_dim % 64 == 0) && g.depth_feature_dim <= 1) {
+        emb_K = tok.K + (g.dino_feature_dim > 0 ? dino.K : 0);
+        emb_wt = alloc<T>((int64_t)d * emb_K); emb_bias = alloc<float>(d);
+        k_pack<T>(c, tok.src[0], d, tok.K, d, nullptr, 0, emb_wt, emb_K);
+        if (g.dino_feature_dim > 0) k_pack<T>(c, dino.src[0], d, dino.K, d, nullptr, 0, emb_wt + tok.K, emb_K);
+        k_sum3(c, tok.bias, g.dino_feature_dim > 0 ? dino.bias : nullptr, g.depth_feature_dim > 0 ? depth.bias : nullptr, emb_bias, d);
+      }
+    }
     enc = make_xf("input_track_transformer", d, g.enc_mlp, g.enc_layers, 0);
     t2l = make_xf("tracks_to_latents", dl, g.t2l_mlp, g.t2l_layers, d);
     comp = make_lin({"compressor/kernel"}, "compressor/bias", dl, g.latent_token_dim);
@@ -176,13 +186,9 @@ template <typename T> struct Net {
     gemm_generic<T>(c, d);
   }
   // Y[M,N] = epi(X[M,K] W + b) (+ residual)
-  struct LnOut { T* out; float* stats; const float* scale; };  // LayerNorm(Y) folded into the GEMM's epilogue where the kernel can (GemmDesc::ln_out)
   void lin_fwd(const Lin<T>& l, const T* X, void* Y, int64_t M, int epi = EPI_NONE, const T* residual = nullptr, int out_f32 = 0,
-               int accumulate = 0, int64_t ldx = 0, int64_t ldy = 0, int crow_group = 0, int crow_skip = 0, T* pre_out = nullptr,
-               const LnOut* ln = nullptr) {
+               int accumulate = 0, int64_t ldx = 0, int64_t ldy = 0, int crow_group = 0, int crow_skip = 0, T* pre_out = nullptr) {
     GemmDesc d{};
-    c->ln_folded = false;
-    if (ln) { d.ln_out = ln->out; d.ln_stats = ln->stats; d.ln_scale = ln->scale; }
     d.A = X; d.B = l.wn; d.C = Y; d.M = M; d.N = l.N; d.K = l.K;
     d.sAm = ldx ? ldx : l.K; d.sAk = 1; d.sBk = l.ldn; d.sBn = 1; d.sCm = ldy ? ldy : l.N;
     d.Bt = l.wt; d.ldBt = l.K;
@@ -205,7 +211,7 @@ template <typename T> struct Net {
     if constexpr (sizeof(T) == 2) {
       // fused projections (q | k | v): ONE dW GEMM over all segments -- X is read once instead of once per segment, a third of the launches --
       // with the output tiles routed to the segments' separate leaves (8-phase TN kernels; else the per-segment loop below)
-      if (l.nseg > 1 && !l.gb && c->gemm_impl != 1 && c->tn_seg && l.gw[0]) {
+      if (l.nseg > 1 && !l.gb && c->gemm_impl != 1 && l.gw[0]) {
         GemmDesc d{};
         d.A = X; d.B = dY; d.C = l.gw[0]; d.M = l.K; d.N = l.N; d.K = M;
         d.sAm = 1; d.sAk = ldx ? ldx : l.K; d.sBk = l.N; d.sBn = 1; d.sCm = l.segw;
@@ -263,13 +269,7 @@ template <typename T> struct Net {
     T* o = alloc<T>(Mg * E); float* lse = alloc<float>(M * H * 2);
     attn_fwd(qkv, qkv + E, qkv + 2 * E, 3 * E, 3 * E, 3 * E, w.sq, w.sk, km, nseq, S, S, o, lse, rg);  // :166-175
     T* a = alloc<T>(Mg * d);
-    T* na = nullptr; float* st2 = nullptr; bool ln2_folded = false;
-    if (!w.cross) {  // LayerNorm 2 (:103-105) rides in the out-projection's epilogue where the kernel owns whole rows (d = 384)
-      na = alloc<T>(Mg * d); st2 = alloc<float>(Mg * 2);
-      const LnOut ln{na, st2, w.norm_attn};
-      lin_fwd(w.out, o, a, Mg, EPI_NONE, x, 0, 0, 0, 0, 0, 0, nullptr, &ln);              // :178-183 + residual :79,90
-      ln2_folded = c->ln_folded;
-    } else lin_fwd(w.out, o, a, Mg, EPI_NONE, x);
+    lin_fwd(w.out, o, a, Mg, EPI_NONE, x);                                              // :178-183 + residual :79,90
     T *cq = nullptr, *ckv = nullptr, *co = nullptr; float* clse = nullptr;
     if (w.cross) {                                                                      // :92-100
       cq = alloc<T>(M * E); lin_fwd(w.cq, nq, cq, M);
@@ -278,8 +278,8 @@ template <typename T> struct Net {
       attn_fwd(cq, ckv, ckv + E, E, 2 * E, 2 * E, w.csq, w.csk, nullptr, nseq, S, Skv, co, clse);
       lin_fwd(w.cout, co, a, M, EPI_NONE, a);
     }
-    if (!na) { na = alloc<T>(Mg * d); st2 = alloc<float>(Mg * 2); }
-    if (!ln2_folded) k_layernorm<T>(c, a, w.norm_attn, na, st2, M, d);                  // :103-105
+    T* na = alloc<T>(Mg * d); float* st2 = alloc<float>(Mg * 2);
+    k_layernorm<T>(c, a, w.norm_attn, na, st2, M, d);                                   // :103-105
     T* hpre = alloc<T>(Mg * w.mlp); T* h = alloc<T>(Mg * w.mlp);
     bool fused = false;
     if constexpr (sizeof(T) == 2) {  // :103-108 as one sequence-resident kernel (track encoder widths): h is never read back from HBM
@@ -446,6 +446,14 @@ template <typename T> struct Net {
     const int64_t nseq = k.nseq;
     const float* tracks = b->support_tracks + b0 * k.N * T_ * NC;
     k.sup_vis = b->support_tracks_visible + b0 * k.N * T_;
+    // embed stage (3d:123-165) as one profile class: algorithmic bytes = what a single pass would move (xyz f32 + visibility + the 16-bit
+    // dino / depth planes in, the kept token rows out); FLOPs of its projections
+    ProfScope* eps = nullptr;
+    {
+      const double rows_in = (double)nseq * T_, kin = (double)(NC + 1) * 2 * nf + (b->dino_features ? g.dino_feature_dim : 0) + (b->depth_features ? g.depth_feature_dim : 0);
+      const double by = rows_in * (NC * 4.0 + 4.0 + ((b->dino_features ? g.dino_feature_dim : 0) + (b->depth_features ? g.depth_feature_dim : 0)) * (double)sizeof(T)) + rows_in * d * (double)sizeof(T);
+      eps = new ProfScope(c, PROF_EMBED, 2.0 * rows_in * kin * d, by);
+    }
     k.sinbuf = alloc<T>(nseq * T_ * (NC + 1) * 2 * nf);
     k_embed_tokens<T>(c, tracks, nseq * T_, T_, nf, g.track_scale_factor, k.sinbuf, NC);             // 3d:126-134 / ta:186-199
     k.km = alloc<float>(nseq * S);
@@ -463,31 +471,55 @@ template <typename T> struct Net {
     }
     const Rag& rg = k.enc_rg;
     const int64_t rows = rg.off ? rg.rows : nseq * S, rows_g = rg.off ? (rows + 7) & ~int64_t(7) : rows;
-    T* tokc = rg.off ? alloc<T>(rows_g * d) : nullptr;
+    k.dino = (!twoD && g.dino_feature_dim > 0 && b->dino_features) ? (const T*)b->dino_features + b0 * k.N * T_ * g.dino_feature_dim : nullptr;
+    k.depthf = (!twoD && g.depth_feature_dim > 0 && b->depth_features) ? (const T*)b->depth_features + b0 * k.N * T_ * g.depth_feature_dim : nullptr;
+    bool emb_done = false;
+    if constexpr (sizeof(T) == 2) {
+      // K1: the three Denses are ONE Dense on the concatenated row (repair R4) -- one GEMM over K = 256 sin features + 768 DINO columns
+      // (two A sources, no concatenated copy), depth as a rank-1 term and the summed biases in the f32 epilogue, every kept token row written
+      // ONCE, straight into the compact (pruned) order; dropped frame tokens are neither computed nor gathered, readout rows come from k_embed_maps
+      if (emb_wt && c->gemm_impl != 1 && (g.dino_feature_dim > 0) == (k.dino != nullptr) && (g.depth_feature_dim > 0) == (k.depthf != nullptr) &&
+          nseq * (int64_t)T_ < 0x7fffffffLL && rows < 0x7fffffffLL) {
+        T* out = alloc<T>(rows_g * d);
+        const int64_t mk_maps = c->ar.mark();
+        int32_t* arow = alloc<int32_t>(rows); int32_t* crow = alloc<int32_t>(rows);
+        k_embed_maps<T>(c, rg.off ? k.row_src : nullptr, rows, S, T_, arow, crow, out, readout, d);
+        GemmDesc e{};
+        e.A = k.sinbuf; e.sAm = tok.K; e.sAk = 1; e.B = emb_wt; e.sBk = 1; e.sBn = emb_K; e.Bt = emb_wt; e.ldBt = emb_K; e.C = out; e.sCm = d;
+        e.M = rows; e.N = d; e.K = emb_K; e.bias = emb_bias; e.arow_idx = arow; e.crow_idx = crow;
+        if (k.dino) { e.A2 = k.dino; e.sA2m = g.dino_feature_dim; e.K1 = tok.K; }
+        if (k.depthf) { e.r1_x = k.depthf; e.r1_w = depth.src[0]; }
+        emb_done = gemm_nt_bf16(c, e);
+        (void)mk_maps;  // (the maps stay allocated for the chunk: the launch is asynchronous)
+        if (emb_done) { k.tok0 = out; }
+      }
+    }
+    T* tokc = (rg.off && !emb_done) ? alloc<T>(rows_g * d) : nullptr;
     const int64_t mk_dense = c->ar.mark();
+    if (!emb_done) {
     k.tok0 = alloc<T>(nseq * S * d);
     // 3DSPA: rows 1..T of every sequence <- Dense(sin) [+ Dense(dino)] [+ Dense(depth)] (3d:137-147); TRAJAN: rows 0..T-1 (ta:211)
     const int cg = twoD ? 0 : T_, cs = twoD ? 0 : 1;
     lin_fwd(tok, k.sinbuf, k.tok0, nseq * T_, EPI_NONE, nullptr, 0, 0, 0, 0, cg, cs);
-    k.dino = nullptr; k.depthf = nullptr;
-    if (!twoD && g.dino_feature_dim > 0 && b->dino_features) {
-      k.dino = (const T*)b->dino_features + b0 * k.N * T_ * g.dino_feature_dim;
-      lin_fwd(dino, (const T*)k.dino, k.tok0, nseq * T_, EPI_NONE, nullptr, 0, 1, 0, 0, T_, 1);
-    }
-    if (!twoD && g.depth_feature_dim > 0 && b->depth_features) {
-      k.depthf = (const T*)b->depth_features + b0 * k.N * T_ * g.depth_feature_dim;
+    if (k.dino) lin_fwd(dino, (const T*)k.dino, k.tok0, nseq * T_, EPI_NONE, nullptr, 0, 1, 0, 0, T_, 1);
+    if (k.depthf) {
       // 1-channel input: a rank-1 update of the token tensor, streamed (as a K=1 GEMM it ran at 1 TB/s); bf16 path only
       if (!(sizeof(T) == 2 && depth.ldn == depth.N && k_rank_fwd<T>(c, (const T*)k.depthf, depth.wn, depth.bias, k.tok0, nseq * T_, depth.N, depth.K, d, T_, 1)))
         lin_fwd(depth, (const T*)k.depthf, k.tok0, nseq * T_, EPI_NONE, nullptr, 0, 1, 0, 0, T_, 1);
     }
     if (!twoD) k_set_readout_rows<T>(c, k.tok0, readout, nseq, S, d);                                // 3d:161-165
+    }
     const T* x = k.tok0;
     const float* km = k.km;
     if (rg.off) {  // compact, then the dense token tensor is dead (the backward rebuilds a dense gradient for the embed dW)
-      k_rows_idx<T>(c, 0, k.tok0, k.row_src, tokc, rows, d);
-      c->ar.release(mk_dense);
-      k.tok0 = tokc; x = tokc; km = nullptr;  // every kept key is visible
+      if (!emb_done) {
+        k_rows_idx<T>(c, 0, k.tok0, k.row_src, tokc, rows, d);
+        c->ar.release(mk_dense);
+        k.tok0 = tokc; x = tokc;
+      }
+      km = nullptr;  // every kept key is visible
     }
+    delete eps;
     const int nenc = (int)enc.blocks.size();
     const int nfull = twoD ? nenc : nenc - 1;  // TRAJAN pools over every frame token: no pruned last block
     k.enc_st.resize(nenc);
@@ -603,6 +635,7 @@ template <typename T> struct Net {
   void grad_segment_done(int i) {
     if (c->dry || !c->last_chunk || !c->grad_ev[i] || c->loss_scale != 1.f) return;
     if (hipEventRecord((hipEvent_t)c->grad_ev[i], c->stream) != hipSuccess && !c->hip_err) { c->hip_err = -6; c->err = "recording a gradient-segment event failed"; }
+    else c->grad_ev_gen[i] += 1;
   }
   // full backward of one chunk; parameter gradients accumulate into G
   void backward_chunk(Chunk& k, const spa3d_batch* b, int64_t b0, const float* denom_dev) {
@@ -616,7 +649,7 @@ template <typename T> struct Net {
       const int64_t mk = c->ar.mark();
       T* dhead = alloc<T>(nq * 4 * To);
       k_loss_bwd<T>(c, k.head, nq, To, b->query_tracks + b0 * k.Q * To * NC, b->query_tracks_visible + b0 * k.Q * To, denom_dev,
-                    L1_WEIGHT, BCE_WEIGHT, dhead, NC, c->loss_scale != 1.f ? denom_dev + 2 : nullptr);  // + loss scale in fp16 mode
+                    L1_WEIGHT, BCE_WEIGHT, dhead, NC, c->loss_scale != 1.f ? denom_dev + 1 : nullptr);  // + loss scale in fp16 mode
       lin_bwd_w(pred, k.q0n, dhead, nq);
       T* dq0n = alloc<T>(nq * dd);
       lin_bwd_x(pred, dhead, dq0n, nq);
@@ -713,7 +746,7 @@ void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
   Net<T> net(c, a.P, a.G);
   net.pack();
   float* sums = net.template alloc<float>(8);
-  float* denom_dev = sums + 4;
+  float* denom_dev = sums + 6;  // [0..5] three 64-bit fixed-point accumulators (kernels.hip loss_acc_add), [6] denominator, [7] loss scale
   k_zero(c, sums, 32);
   const float* noise = b->noise;
   if (a.mode != MODE_ENCODE && b->discretize && !noise) {
@@ -722,9 +755,9 @@ void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
     noise = nb;
   }
   if (train) {
-    k_vis_count(c, b->query_tracks_visible, (int64_t)b->B * b->Q * To, sums + 2);
+    k_vis_count(c, b->query_tracks_visible, (int64_t)b->B * b->Q * To, sums + 4);
     k_set_denom(c, sums, a.denom, denom_dev);
-    if (c->loss_scale != 1.f) k_set_loss_scale(c, denom_dev, L1_WEIGHT, c->loss_scale, denom_dev + 2);  // sums[6]
+    if (c->loss_scale != 1.f) k_set_loss_scale(c, denom_dev, L1_WEIGHT, c->loss_scale, denom_dev + 1);  // sums[7]
     if (!a.accumulate) k_zero(c, a.G, c->nparams * 4);
   }
   for (int64_t b0 = 0; b0 < b->B; b0 += Bc) {
@@ -732,6 +765,10 @@ void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
     c->last_chunk = b0 + Bc >= b->B;
     k.Bc = std::min<int64_t>(Bc, b->B - b0); k.N = b->N; k.Q = b->Q; k.T_ = b->T; k.S = b->T + (g.model_kind == 1 ? 0 : 1); k.nseq = k.Bc * b->N;
     const int64_t mk = c->ar.mark();
+    if (c->poison && !c->dry) {  // test mode: everything this chunk may allocate starts as NaN (0xFFFF / 0xFFFFFFFF) instead of the previous chunk's values
+      const int64_t o = (mk + 255) & ~int64_t(255);
+      if (o < c->ar.cap) (void)hipMemsetAsync(c->ar.base + o, 0xFF, (size_t)(c->ar.cap - o), c->stream);
+    }
     const float* lat = nullptr;
     if (a.mode != MODE_DECODE) {
       net.encode_chunk(k, b, b0, train);
@@ -754,7 +791,7 @@ void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
     }
     c->ar.release(mk);
   }
-  if (train && c->loss_scale != 1.f) k_unscale(c, a.G, denom_dev + 2, c->nparams);  // fp32 gradient buffer back to true scale (exact: power of two)
+  if (train && c->loss_scale != 1.f) k_unscale(c, a.G, denom_dev + 1, c->nparams);  // fp32 gradient buffer back to true scale (exact: power of two)
   if (train && a.loss3) k_loss_finalize(c, sums, denom_dev, L1_WEIGHT, BCE_WEIGHT, a.loss3);
 }
 
@@ -867,6 +904,7 @@ static int run(spa3d_ctx* c, RunArgs a, void* ws, int64_t ws_bytes, void* stream
   if (rc) return rc;
   c->stream = (hipStream_t)stream;
   int lo = 1, hi = a.b->B;
+  if (a.chunk <= 0) a.chunk = c->chunk;  // spa3d_set_option "chunk" / SPA3D_CHUNK: fixed samples per chunk (tests: chunk-to-chunk reuse of the arena)
   if (a.chunk > 0) { lo = hi = std::min(a.chunk, a.b->B); }
   if (dry_need(c, a, lo) > ws_bytes) {
     c->err = "workspace too small: need " + std::to_string(dry_need(c, a, lo)) + " bytes for chunk " + std::to_string(lo);
@@ -907,23 +945,13 @@ int spa3d_create(const spa3d_config* cfg, spa3d_handle* out) {
   // at loss x 2^k (k chosen per call from the loss denominator, k_set_loss_scale) and the fp32 parameter gradients are scaled back once
   // at the end (exact for powers of two)
   if (cfg->precision == SPA3D_F16) c->loss_scale = -16.f;
-  const char* e = getenv("SPA3D_GEMM_IMPL"); if (e) c->gemm_impl = atoi(e);
+  // the six switches (include/spa3d.h, spa3d_set_option) may be preset from the environment; nothing else is read from it
+  const char* e = getenv("SPA3D_GEMM_IMPL"); if (e) apply_gemm_impl(c, atoi(e));
+  e = getenv("SPA3D_ATTN_IMPL"); if (e) apply_attn_impl(c, atoi(e));
   e = getenv("SPA3D_LOSS_SCALE"); if (e && cfg->precision == SPA3D_F16) c->loss_scale = (float)atof(e);
-  e = getenv("SPA3D_ATTN_IMPL"); if (e) c->attn_impl = atoi(e);
-  e = getenv("SPA3D_ATTN_BWD_MODE"); if (e) c->attn_bwd_mode = atoi(e);
   e = getenv("SPA3D_PRUNE"); if (e) c->prune = atoi(e);
   e = getenv("SPA3D_RO_SHARE"); if (e) c->ro_share = atoi(e);
-  e = getenv("SPA3D_NT_OCC"); if (e) c->nt_occ = atoi(e);
-  e = getenv("SPA3D_NT_8P"); if (e) c->nt_8p = atoi(e);
-  e = getenv("SPA3D_NT_8PP"); if (e) c->nt_8pp = atoi(e);
-  e = getenv("SPA3D_NT_COARSE"); if (e) c->nt_coarse = atoi(e);
-  e = getenv("SPA3D_NT_STREAM"); if (e) c->nt_stream = atoi(e);
-  e = getenv("SPA3D_TN_8P"); if (e) c->tn_8p = atoi(e);
-  e = getenv("SPA3D_TN_QP"); if (e) c->tn_qp = atoi(e);
-  e = getenv("SPA3D_TN_ROUNDS"); if (e) c->tn_rounds = atoi(e);
-  e = getenv("SPA3D_TN_SEG"); if (e) c->tn_seg = atoi(e);
-  e = getenv("SPA3D_LN_FOLD"); if (e) c->ln_fold = atoi(e);
-  e = getenv("SPA3D_MLP_FUSED"); if (e) c->mlp_fused = atoi(e);
+  e = getenv("SPA3D_CHUNK"); if (e) c->chunk = atoi(e);
   *out = c;
   return SPA3D_OK;
 }
@@ -944,8 +972,13 @@ int spa3d_leaf_info(spa3d_handle h, int32_t i, char* name, int32_t* ndim, int64_
 int64_t spa3d_workspace_bytes(spa3d_handle h, int32_t B, int32_t N, int32_t Q, int32_t T, int32_t chunk, int32_t train) {
   if (!h || B <= 0 || N <= 0 || Q <= 0 || T <= 0) return -1;
   spa3d_batch b{}; b.B = B; b.N = N; b.Q = Q; b.T = T; b.discretize = 1;
-  b.dino_features = h->cfg.dino_feature_dim > 0 ? (const void*)0x100000 : nullptr;
-  b.depth_features = h->cfg.depth_feature_dim > 0 ? (const void*)0x100000 : nullptr;
+  // never dereferenced (the dry run launches nothing), but the orchestration offsets them per chunk: arithmetic on a null pointer is undefined
+  // behaviour (UBSan, tests/test_host_sanitizers.py), so the dummy batch points at a fake non-null base
+  const float* fake = (const float*)(uintptr_t)0x100000;
+  b.support_tracks = fake; b.support_tracks_visible = fake; b.query_points = fake; b.boundary_frame = (const int32_t*)fake;
+  b.query_tracks = fake; b.query_tracks_visible = fake;
+  b.dino_features = h->cfg.dino_feature_dim > 0 ? (const void*)fake : nullptr;
+  b.depth_features = h->cfg.depth_feature_dim > 0 ? (const void*)fake : nullptr;
   RunArgs a{}; a.mode = train ? MODE_TRAIN : MODE_FORWARD; a.b = &b; a.G = train ? (float*)0x100000 : nullptr;
   return dry_need(h, a, std::max(1, std::min(chunk, B)));
 }
@@ -971,7 +1004,6 @@ int spa3d_loss_and_grads(spa3d_handle h, const float* params, const spa3d_batch*
   if (!h || !params || !grads) return SPA3D_ERR_ARG;
   if (accumulate && h->loss_scale != 1.f) { h->err = "accumulate=1 is not supported with a loss scale (fp16 mode)"; return SPA3D_ERR_ARG; }
   RunArgs a{}; a.mode = MODE_TRAIN; a.P = params; a.b = b; a.denom = denom; a.G = grads; a.accumulate = accumulate; a.loss3 = loss3; a.out = out;
-  const char* e = getenv("SPA3D_CHUNK"); if (e) a.chunk = atoi(e);
   return run(h, a, ws, ws_bytes, stream);
 }
 
@@ -979,13 +1011,14 @@ int spa3d_loss(spa3d_handle h, const spa3d_batch* b, const spa3d_outputs* preds,
   if (!h || !b || !preds || !loss3 || !preds->tracks || !preds->visible_logits || !b->query_tracks || !b->query_tracks_visible)
     return SPA3D_ERR_ARG;
   h->err.clear(); h->hip_err = 0; h->stream = (hipStream_t)stream; h->dry = false;
-  float* scratch = loss3 + 4;  // loss3 points at 12 floats: [0..2] results, [4..11] scratch
+  if (((uintptr_t)loss3) & 7) { h->err = "loss3 must be 8-byte aligned"; return SPA3D_ERR_ARG; }
+  float* scratch = loss3 + 4;  // loss3 points at 12 floats: [0..2] results, [4..9] three 64-bit fixed-point accumulators, [10] denominator
   const int64_t n = (int64_t)b->B * b->Q * h->cfg.num_output_frames;
   k_zero(h, scratch, 32);
-  k_vis_count(h, b->query_tracks_visible, n, scratch + 2);
-  k_set_denom(h, scratch, denom, scratch + 4);
+  k_vis_count(h, b->query_tracks_visible, n, scratch + 4);
+  k_set_denom(h, scratch, denom, scratch + 6);
   k_loss_from_preds(h, preds->tracks, preds->visible_logits, n, b->query_tracks, b->query_tracks_visible, scratch, h->cfg.model_kind == 1 ? 2 : 3);
-  k_loss_finalize(h, scratch, scratch + 4, L1_WEIGHT, BCE_WEIGHT, loss3);
+  k_loss_finalize(h, scratch, scratch + 6, L1_WEIGHT, BCE_WEIGHT, loss3);
   return h->hip_err ? SPA3D_ERR_HIP : SPA3D_OK;
 }
 
@@ -995,10 +1028,10 @@ int spa3d_set_option(spa3d_handle h, const char* name, double value) {
   if (n == "prune") h->prune = value != 0;
   else if (n == "ro_share") h->ro_share = value != 0;
   else if (n == "loss_scale") { if (h->cfg.precision != SPA3D_F16) { h->err = "loss_scale applies to SPA3D_F16 handles only"; return SPA3D_ERR_ARG; } h->loss_scale = (float)value; }
-  else if (n == "attn_bwd_mode") h->attn_bwd_mode = (int)value;
-  else if (n == "attn_impl") h->attn_impl = (int)value;
-  else if (n == "gemm_impl") h->gemm_impl = (int)value;
-  else if (n == "mlp_fused") h->mlp_fused = value != 0;
+  else if (n == "attn_impl") apply_attn_impl(h, (int)value);
+  else if (n == "gemm_impl") apply_gemm_impl(h, (int)value);
+  else if (n == "chunk") h->chunk = value > 0 ? (int)value : 0;
+  else if (n == "poison") h->poison = value != 0;
   else { h->err = "unknown option: " + n; return SPA3D_ERR_ARG; }
   return SPA3D_OK;
 }
@@ -1016,6 +1049,17 @@ int spa3d_grad_segments(spa3d_handle h, int64_t* bounds4) {
   }
   if (b1 < 0 || b2 < b1) return SPA3D_ERR_ARG;
   bounds4[0] = 0; bounds4[1] = b1; bounds4[2] = b2; bounds4[3] = h->nparams;
+  return SPA3D_OK;
+}
+int spa3d_grad_events_recorded(spa3d_handle h, int64_t* out4) {
+  if (!h || !out4) return SPA3D_ERR_ARG;
+  out4[0] = h->grad_ev_gen[0]; out4[1] = h->grad_ev_gen[1]; out4[2] = (int64_t)(intptr_t)h->grad_ev[0]; out4[3] = (int64_t)(intptr_t)h->grad_ev[1];
+  return SPA3D_OK;
+}
+int spa3d_detach(spa3d_handle h, void* ev_readout, void* ev_latents, const float* loss_scale_state) {
+  if (!h) return SPA3D_ERR_ARG;
+  if (ev_readout && h->grad_ev[0] == ev_readout && h->grad_ev[1] == ev_latents) { h->grad_ev[0] = nullptr; h->grad_ev[1] = nullptr; }
+  if (loss_scale_state && h->loss_scale_state == loss_scale_state) h->loss_scale_state = nullptr;
   return SPA3D_OK;
 }
 int spa3d_set_grad_events(spa3d_handle h, void* ev_readout, void* ev_latents) {
@@ -1048,7 +1092,7 @@ int spa3d_prof_read(spa3d_handle h, int32_t cls, double* out4) {
   return SPA3D_OK;
 }
 
-// Debug aid (not part of include/spa3d.h): one CSV line per profiled launch group: cls,ms,flops,bytes,tag0..3
+// one CSV line per profiled launch group: cls,ms,flops,bytes,tag0..3 (include/spa3d.h)
 int spa3d_prof_dump(spa3d_handle h, const char* path) {
   if (!h || !path) return SPA3D_ERR_ARG;
   FILE* f = fopen(path, "w");

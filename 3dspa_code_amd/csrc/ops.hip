@@ -8,17 +8,8 @@
 namespace SPA_NS {
 namespace {
 struct OpCtx : spa3d_ctx {
-  OpCtx(void* stream_, void* ws, int64_t ws_bytes) {
+  OpCtx(void* stream_, void* ws, int64_t ws_bytes) {  // (no environment switches: kernel choice comes from the entry point's `impl` argument)
     stream = (hipStream_t)stream_; ar.base = (char*)ws; ar.cap = ws_bytes;
-    const char* e = getenv("SPA3D_NT_OCC"); if (e) nt_occ = atoi(e);
-    e = getenv("SPA3D_NT_8P"); if (e) nt_8p = atoi(e);
-    e = getenv("SPA3D_ATTN_BWD_MODE"); if (e) attn_bwd_mode = atoi(e);
-    e = getenv("SPA3D_NT_8PP"); if (e) nt_8pp = atoi(e);
-    e = getenv("SPA3D_NT_COARSE"); if (e) nt_coarse = atoi(e);
-    e = getenv("SPA3D_NT_STREAM"); if (e) nt_stream = atoi(e);
-    e = getenv("SPA3D_TN_8P"); if (e) tn_8p = atoi(e);
-    e = getenv("SPA3D_TN_QP"); if (e) tn_qp = atoi(e);
-    e = getenv("SPA3D_TN_ROUNDS"); if (e) tn_rounds = atoi(e);
   }
   template <typename U> U* alloc(int64_t n) { return (U*)ar.alloc(n * (int64_t)sizeof(U)); }
   int status() { return ar.overflow ? SPA3D_ERR_WORKSPACE : (hip_err ? SPA3D_ERR_HIP : SPA3D_OK); }
@@ -29,32 +20,33 @@ int op_linear(OpCtx& c, const T* A, const T* B, const float* bias, const T* res,
   GemmDesc d{};
   d.A = A; d.B = B; d.C = C; d.M = M; d.N = N; d.K = K; d.sAm = K; d.sAk = 1; d.sBk = N; d.sBn = 1; d.sCm = N;
   d.bias = bias; d.epi = act ? EPI_GELU : EPI_NONE; d.aux = res;
+  apply_gemm_impl(&c, impl & 15);
   if constexpr (sizeof(T) == 2) {
     if (impl != 1) {
-      // measurement aid (tools/bench_ln_fold.py): a second output stream of the same size from the epilogue = what folding a LayerNorm's output
-      // into this GEMM would add to it
-      if (getenv("SPA3D_OP_PREOUT")) { d.pre_out = c.alloc<T>(M * N); if (c.ar.overflow) return SPA3D_ERR_WORKSPACE; }
+      // impl | 16 (benchmarks): the MLP-in form of the step -- a second output stream (the pre-activation) from the same epilogue
+      if (impl & 16) { d.pre_out = c.alloc<T>(M * N); if (c.ar.overflow) return SPA3D_ERR_WORKSPACE; }
       T* Bt = c.alloc<T>((int64_t)K * N);
       if (c.ar.overflow) return SPA3D_ERR_WORKSPACE;
       k_transpose<T>(&c, B, K, N, Bt);
       d.Bt = Bt; d.ldBt = K;
       if (gemm_nt_bf16(&c, d)) return c.status();
-      if (impl == 2) return SPA3D_ERR_ARG;
+      if ((impl & 15) >= 2) return SPA3D_ERR_ARG;
     }
-  } else if (impl == 2) return SPA3D_ERR_ARG;
+  } else if ((impl & 15) >= 2) return SPA3D_ERR_ARG;
   gemm_generic<T>(&c, d);
   return c.status();
 }
 
 template <typename T>
 int op_linear_bwd(OpCtx& c, const T* A, const T* B, const T* dC, T* dA, float* dB, float* dbias, int64_t M, int N, int K, int impl) {
+  apply_gemm_impl(&c, impl);
   if (dA) {  // dA[M,K] = dC[M,N] . B[K,N]^T
     GemmDesc d{};
     d.A = dC; d.B = B; d.C = dA; d.M = M; d.N = K; d.K = N; d.sAm = N; d.sAk = 1; d.sBk = 1; d.sBn = N; d.sCm = K;
     d.Bt = B; d.ldBt = N;
     bool done = false;
     if constexpr (sizeof(T) == 2) { if (impl != 1) done = gemm_nt_bf16(&c, d); }
-    if (!done) { if (impl == 2) return SPA3D_ERR_ARG; gemm_generic<T>(&c, d); }
+    if (!done) { if (impl >= 2) return SPA3D_ERR_ARG; gemm_generic<T>(&c, d); }
   }
   if (dB) {  // dB[K,N] = A[M,K]^T . dC[M,N]
     k_zero(&c, dB, (int64_t)K * N * 4);
@@ -64,7 +56,7 @@ int op_linear_bwd(OpCtx& c, const T* A, const T* B, const T* dC, T* dA, float* d
     void* zp = c.alloc<char>(256); k_zero(&c, zp, 256); d.zero_page = zp;
     bool done = false;
     if constexpr (sizeof(T) == 2) { if (impl != 1) done = gemm_tn_bf16(&c, d); }
-    if (!done) { if (impl == 2) return SPA3D_ERR_ARG; gemm_generic<T>(&c, d); }
+    if (!done) { if (impl >= 2) return SPA3D_ERR_ARG; gemm_generic<T>(&c, d); }
   }
   if (dbias) { k_zero(&c, dbias, (int64_t)N * 4); k_colsum<T>(&c, dC, M, N, N, dbias); }
   return c.status();
@@ -184,12 +176,13 @@ int spa3d_op_attention(const void* q, const void* k, const void* v, int64_t ldq,
   FWD16(spa3d_op_attention_f16(q, k, v, ldq, ldk, ldv, scale_q, scale_k, keymask, nseq, Sq, Sk, H, Dh, o, lse, dtype, impl, ws, ws_bytes, stream))
   if (!q || !k || !v || !o || !scale_q || !scale_k || Dh > 128) return SPA3D_ERR_ARG;
   OpCtx c(stream, ws, ws_bytes);
+  apply_attn_impl(&c, impl);
   if (dtype == SPA3D_F32)
     attention_fwd<float>(&c, (const float*)q, (const float*)k, (const float*)v, ldq, ldk, ldv, scale_q, scale_k, keymask, nseq, Sq, Sk, H, Dh,
-                         (float*)o, lse, impl);
+                         (float*)o, lse, c.attn_impl);
   else
     attention_fwd<bf16_t>(&c, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, scale_q, scale_k, keymask, nseq, Sq, Sk, H,
-                          Dh, (bf16_t*)o, lse, impl);
+                          Dh, (bf16_t*)o, lse, c.attn_impl);
   return c.status();
 }
 int spa3d_op_attention_bwd(const void* q, const void* k, const void* v, int64_t ldq, int64_t ldk, int64_t ldv, const float* scale_q,
@@ -201,12 +194,13 @@ int spa3d_op_attention_bwd(const void* q, const void* k, const void* v, int64_t 
                                    dscale_k, dtype, impl, ws, ws_bytes, stream))
   if (!q || !k || !v || !d_o || !dq || !dk || !dv || !dscale_q || !dscale_k || Dh > 128) return SPA3D_ERR_ARG;
   OpCtx c(stream, ws, ws_bytes);
+  apply_attn_impl(&c, impl);
   if (dtype == SPA3D_F32)
     attention_bwd<float>(&c, (const float*)q, (const float*)k, (const float*)v, ldq, ldk, ldv, scale_q, scale_k, keymask, nseq, Sq, Sk, H, Dh,
-                         (const float*)o, lse, (const float*)d_o, (float*)dq, (float*)dk, (float*)dv, dscale_q, dscale_k, impl);
+                         (const float*)o, lse, (const float*)d_o, (float*)dq, (float*)dk, (float*)dv, dscale_q, dscale_k, c.attn_impl);
   else
     attention_bwd<bf16_t>(&c, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, scale_q, scale_k, keymask, nseq, Sq, Sk, H,
-                          Dh, (const bf16_t*)o, lse, (const bf16_t*)d_o, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, dscale_q, dscale_k, impl);
+                          Dh, (const bf16_t*)o, lse, (const bf16_t*)d_o, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, dscale_q, dscale_k, c.attn_impl);
   return c.status();
 }
 

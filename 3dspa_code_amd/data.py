@@ -94,6 +94,8 @@ def save_checkpoint(path: str, params, state=None):
     flat.update({f'opt_m/{k}': t.detach().cpu().numpy() for k, t in _flatten(m_tree).items()})
     flat.update({f'opt_v/{k}': t.detach().cpu().numpy() for k, t in _flatten(v_tree).items()})
     flat['step'] = np.array(state.step, dtype=np.int64)
+    # skipped-step counter, dynamic loss-scale multiplier and its good-step counter (spa3d_adamw_step scratch[3..5]) belong to the optimizer state
+    flat['opt_scratch'] = state.scratch[3:6].detach().cpu().numpy()
     assert names
   if not path.endswith('.npz'):
     path = path + '.npz'
@@ -125,7 +127,7 @@ def load_checkpoint(checkpoint_path: str, model=None, allow_pickle: bool = False
     opt = opt.item() if opt.ndim == 0 else dict(opt)
     params = opt.get('target', opt) if isinstance(opt, dict) else opt
   else:
-    flat = {k: np.array(data[k]) for k in data.files if not (k.startswith('opt_m/') or k.startswith('opt_v/') or k == 'step')}
+    flat = {k: np.array(data[k]) for k in data.files if not (k.startswith('opt_m/') or k.startswith('opt_v/') or k in ('step', 'opt_scratch'))}
     params = _unflatten_params(flat)
   return params
 
@@ -220,6 +222,12 @@ def restore_flax_checkpoint(ckpt_dir: str, prefix: str = 'checkpoint_'):
     return msgpack_restore(f.read())
 
 
+def _group_src(group, src: int = 0) -> int:
+  """dist.broadcast takes a GLOBAL rank; `src` is a rank of `group` (a sub-group's rank 0 is generally not global rank 0)."""
+  import torch.distributed as dist
+  return dist.get_global_rank(group, src) if group is not None else src
+
+
 def load_train_state(checkpoint_path: str, state, rank0_only: bool = False):
   """Resume: parameters, Adam moments and step back into a TrainState (in place).  Under data parallelism every replica ends
   with rank 0's state: with `rank0_only` only rank 0 reads the file and the buffers + step are broadcast."""
@@ -228,7 +236,7 @@ def load_train_state(checkpoint_path: str, state, rank0_only: bool = False):
   if multi and rank0_only and state.rank != 0:
     step = torch.zeros(1, dtype=torch.int64, device=state.flat.device)
     state.sync_from_rank0()
-    dist.broadcast(step, src=0, group=state.pg)
+    dist.broadcast(step, src=_group_src(state.pg), group=state.pg)
     state.step = int(step.item())
     return state
   data = np.load(checkpoint_path, allow_pickle=False)
@@ -246,8 +254,10 @@ def load_train_state(checkpoint_path: str, state, rank0_only: bool = False):
         raise ValueError(f'shape mismatch for {key}: expected {shape}, got {a.shape}')
       buf[off:off + n] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).reshape(-1).to(buf.device)
   state.step = int(data['step'])
+  if 'opt_scratch' in data.files:  # absent in checkpoints written before round 4: counters start at 0, multiplier at 1
+    state.scratch[3:6] = torch.from_numpy(np.asarray(data['opt_scratch'], dtype=np.float32)).to(state.scratch.device)
   if multi:
     state.sync_from_rank0()
     if rank0_only:
-      dist.broadcast(torch.tensor([state.step], dtype=torch.int64, device=state.flat.device), src=0, group=state.pg)
+      dist.broadcast(torch.tensor([state.step], dtype=torch.int64, device=state.flat.device), src=_group_src(state.pg), group=state.pg)
   return state

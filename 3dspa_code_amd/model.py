@@ -492,7 +492,8 @@ class TrackAutoEncoder(TrackAutoEncoder3D):
 
 
 PROF_CLASSES = ('gemm_nt_bf16 (tiled MFMA, Y=X.W / dX=dY.W^T)', 'gemm_tn_bf16 (tiled MFMA, dW=X^T.dY)', 'gemm_generic (strided MFMA)',
-                'attention_fused_fwd', 'attention_fused_bwd', 'layernorm_fwd', 'layernorm_bwd', 'attention_single_query (pruned last block)')
+                'attention_fused_fwd', 'attention_fused_bwd', 'layernorm_fwd', 'layernorm_bwd', 'attention_single_query (pruned last block)',
+                'embed (sin features + token / dino / depth projections + readout row + prune gather; its GEMMs also count in gemm_nt_bf16)')
 
 
 def profile_summary(model, handle, peak_flops: float = 2.5e15):

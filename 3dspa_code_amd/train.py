@@ -38,14 +38,25 @@ def _collectives_on(group=None, force=False) -> bool:
   return force or dist.get_world_size(group) > 1
 
 
-def global_visible_count(visible: torch.Tensor, group=None, force=False) -> float:
+def global_visible_count(visible: torch.Tensor, group=None, force=False, check_equal_batches: bool = False) -> float:
   """max(sum(query_tracks_visible) over ALL ranks, 1): both loss terms divide by the batch-global visible count
   (train.py:111-113,119-121), so under data parallelism it is one scalar all-reduce BEFORE the backward.  The C-ABI takes the
-  denominator by value, so this is one 4-byte device->host read per step (the only host sync of the multi-GPU step)."""
-  s = visible.to(torch.float32).sum()
+  denominator by value, so this is one 4-byte device->host read per step (the only host sync of the multi-GPU step).
+  `check_equal_batches`: the same collective also carries (B_local, B_local^2), so EVERY rank checks EVERY step that all ranks hold the same
+  local batch (world * sum(B^2) == (sum B)^2) and all of them raise together -- a check issued by only some ranks (e.g. on a cache miss)
+  would leave the others in the next collective and hang the job instead."""
+  b = float(visible.shape[0])
+  s = torch.stack([visible.to(torch.float32).sum(), visible.new_tensor(b, dtype=torch.float32), visible.new_tensor(b * b, dtype=torch.float32)])
   if _collectives_on(group, force):
     dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
-  return max(float(s.item()), 1.0)
+    h = s.tolist()
+    if check_equal_batches:
+      world = dist.get_world_size(group)
+      if world * h[2] != h[1] * h[1]:
+        raise ValueError(f'local batch sizes differ across ranks (this rank: {int(b)}, mean {h[1] / world:g}); the global discretisation '
+                         'noise is sliced by equal per-rank batches and the gradient SUM assumes them')
+    return max(h[0], 1.0)
+  return max(float(s[0].item()), 1.0)
 
 
 def allreduce_flat_(flat: torch.Tensor, bucket_elems: int, group=None, extra=(), force=False):
@@ -157,8 +168,11 @@ class TrainState:
       evs = (torch.cuda.Event(), torch.cuda.Event())
       for e in evs:
         e.record()  # instantiates the underlying hipEvent_t
+      # last writer wins on the handle (one state trains a model at a time): a state replaced here keeps its own events but they are no
+      # longer recorded, which train_step detects through spa3d_grad_events_recorded and answers with the stream-ordered all-reduce
       _lib.check(lib.spa3d_set_grad_events(h, C.c_void_p(evs[0].cuda_event), C.c_void_p(evs[1].cuda_event)), h, 'spa3d_set_grad_events')
       self._overlap = (tuple(int(x) for x in b4), evs, torch.cuda.Stream(device=flat.device))
+      self._ev_gen = self._events_recorded()
     if model.precision == 'fp16' and compute is None and adamw is None:
       # dynamic loss scale: spa3d_adamw_step skips a step whose gradient norm is inf/NaN and halves the multiplier kept in scratch[4],
       # which the next spa3d_loss_and_grads on this handle applies (include/spa3d.h)
@@ -167,18 +181,29 @@ class TrainState:
       self._scale_state_on = True
     self.sync_from_rank0()
 
+  def _events_recorded(self):
+    h = self.model._handle(*self.model._dims_from_params(self.params))[0]
+    g4 = (C.c_int64 * 4)()
+    _lib.check(_lib.load().spa3d_grad_events_recorded(h, g4), h, 'spa3d_grad_events_recorded')
+    mine = self._overlap is not None and int(g4[2]) == int(self._overlap[1][0].cuda_event) and int(g4[3]) == int(self._overlap[1][1].cuda_event)
+    return int(g4[0]), int(g4[1]), mine
+
   def close(self):
-    """Detach what this state registered on the model's handle (gradient-segment events, the loss-scale state in `scratch`): the handle
-    outlives the state (it belongs to the model), the events and the scratch buffer do not."""
+    """Detach what THIS state registered on the model's handle (gradient-segment events, the loss-scale state in `scratch`): the handle
+    outlives the state (it belongs to the model), the events and the scratch buffer do not.  Owner-aware (spa3d_detach compares pointers):
+    a state created later on the same model -- a resume, `state = TrainState(model, ...)` rebinding, whose predecessor's __del__ runs
+    AFTER the new constructor -- keeps its registration."""
     try:
       lib = _lib.load()
       h = self.model._handle(*self.model._dims_from_params(self.params))[0]
-      if getattr(self, '_overlap', None) is not None:
-        lib.spa3d_set_grad_events(h, None, None)
-        self._overlap = None
-      if getattr(self, '_scale_state_on', False):
-        lib.spa3d_set_loss_scale_state(h, None)
-        self._scale_state_on = False
+      ov = getattr(self, '_overlap', None)
+      scale = self.scratch.data_ptr() + 16 if getattr(self, '_scale_state_on', False) else None
+      if ov is not None or scale is not None:
+        e0 = C.c_void_p(ov[1][0].cuda_event) if ov is not None else None
+        e1 = C.c_void_p(ov[1][1].cuda_event) if ov is not None else None
+        lib.spa3d_detach(h, e0, e1, C.c_void_p(scale) if scale is not None else None)
+      self._overlap = None
+      self._scale_state_on = False
     except Exception:
       pass
 
@@ -209,13 +234,7 @@ class TrainState:
     """The reference draws uniform(PRNGKey(0), [B_global, L, Ld]) over the GLOBAL batch (3d:254-258); rank r owns rows
     r*B_local .. of that tensor, not a draw of its own over [B_local, L, Ld].  Fixed key => drawn once and cached."""
     key = (b_local, self.world, self.rank)
-    if key not in self._noise_cache:
-      if self.world > 1:  # the slice arithmetic below needs the same local batch on every rank
-        sizes = torch.tensor([b_local, -b_local], dtype=torch.int64, device=self.flat.device)
-        dist.all_reduce(sizes, op=dist.ReduceOp.MAX, group=self.pg)
-        if int(sizes[0]) != b_local or int(-sizes[1]) != b_local:
-          raise ValueError(f'rank {self.rank}: local batch {b_local} differs across ranks (max {int(sizes[0])}, min {int(-sizes[1])}); '
-                           'the global discretisation noise is sliced by equal per-rank batches')
+    if key not in self._noise_cache:  # (equal local batches are checked every step inside global_visible_count's all-reduce)
       L, Ld = self.model.num_latent_tokens, self.model.latent_token_dim
       full = self._noise_fn(b_local * self.world * L * Ld, self.flat.device).view(self.world, b_local, L, Ld)
       self._noise_cache = {key: full[self.rank].clone()}
@@ -223,19 +242,27 @@ class TrainState:
 
   def train_step(self, batch, discretize: bool = True, noise=None):
     multi = self.world > 1 or self.force
-    denom = global_visible_count(batch['query_tracks_visible'], self.pg, self.force) if multi else 0.0
+    denom = global_visible_count(batch['query_tracks_visible'], self.pg, self.force, check_equal_batches=True) if multi else 0.0
     if multi and discretize and noise is None:
       noise = self.rank_noise(batch['query_tracks_visible'].shape[0])
     ld = self._compute(self.params, batch, self.grads, denom, discretize, noise)
     l3 = torch.stack([torch.as_tensor(ld[k], dtype=torch.float32, device=self.flat.device).reshape(())
                       for k in ('total_loss', 'position_loss', 'visible_loss')])
     # the per-rank gradients and loss terms already carry the global 1/denominator -> plain SUM over ranks
+    use_overlap = False
     if self._overlap is not None and multi:
+      gen = self._events_recorded()  # did THIS call record both segment events?  (another state may own the handle's events by now)
+      use_overlap = gen[2] and gen[0] == self._ev_gen[0] + 1 and gen[1] == self._ev_gen[1] + 1
+      self._ev_gen = gen
+    if use_overlap:
       bounds, evs, side = self._overlap
       allreduce_segments_overlapped_(self.grads, bounds, evs, side, self.bucket_elems, self.pg, extra=(l3,))
     else:
       allreduce_flat_(self.grads, self.bucket_elems, self.pg, extra=(l3,), force=self.force)
     lr = self.schedule(self.step)
+    # `step` counts CALLS.  A skipped update (non-finite gradient norm; scratch[3] counts them on the device) leaves m and v untouched, and
+    # spa3d_adamw_step takes the Adam bias correction at step - skipped, so the optimizer count does not run ahead of the moments; the
+    # learning-rate schedule is host arithmetic on `step` and does advance through a skip (reading the counter back would cost a sync).
     self._adamw(self.flat, self.grads, self.m, self.v, lr, self.step, self.clip, self.b1, self.b2, self.eps, self.wd, self.scratch)
     self.step += 1
     # metric keys of train.py:180-185 (device scalars)
@@ -249,7 +276,7 @@ class TrainState:
     loss terms are normalised by the GLOBAL visible count and summed over ranks, exactly as the training loss is, and the rank
     takes its slice of the global discretisation noise; predictions are the rank's own."""
     multi = self.world > 1 or self.force
-    denom = global_visible_count(batch['query_tracks_visible'], self.pg, self.force) if multi else 0.0
+    denom = global_visible_count(batch['query_tracks_visible'], self.pg, self.force, check_equal_batches=True) if multi else 0.0
     if multi and discretize and noise is None:
       noise = self.rank_noise(batch['query_tracks_visible'].shape[0])
     ld, preds = self._evaluate(self.params, batch, denom, discretize, noise)

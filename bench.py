@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- train-step tracks/sec of the 3DSPA hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W [--config {1,2,3}]
+  python bench.py --gpus N --steps K --warmup W [--config {1,2,3,5}] [--batch B]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Called WITHOUT a torchrun environment and --gpus N > 1, bench.py starts the N ranks itself: before anything touches a GPU it runs
@@ -13,7 +13,9 @@ one JSON line and all exit -- the launch path is testable on a CPU-only host (te
 One step = forward + compute_loss_3d + backward + (RCCL gradient all-reduce) + clip/AdamW over one synthetic
 batch resident in HBM.  Default workload at every N: BASELINE.json configs[2] per GPU (B=64, 2048 support + 512 query,
 T=150, xyz+depth+DINOv2-768, bf16) => weak scaling; configs[3] is exactly this at N=8 (global B=512).
---config 2: configs[1] (xyz+depth only, C=4); --config 1: configs[0]'s shape (B=2, 64+16 tracks, T=24, xyz-only, fp32) on the GPU.
+--config 2: configs[1] (xyz+depth only, C=4); --config 1: configs[0]'s shape (B=2, 64+16 tracks, T=24, xyz-only, fp32) on the GPU;
+--config 5: configs[4], the stress shape (8192 support + 2048 query, T = T_out = 300, C=772, fp16) with --batch samples per GPU (default 8:
+3.8 GB of input per sample).
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
 """
 from __future__ import annotations
@@ -42,6 +44,7 @@ CONFIGS = {
     1: dict(B=2, N=64, Q=16, T=24, dino=0, depth=0, precision='fp32', name='BASELINE configs[0] shape on the GPU: B=2, 64 support + 16 query, T=24, xyz-only, fp32'),
     2: dict(B=64, N=2048, Q=512, T=150, dino=0, depth=1, precision='bf16', name='BASELINE configs[1] per GPU: B=64, 2048 support + 512 query, T=150, xyz+depth(1) (C=4)'),
     3: dict(B=64, N=2048, Q=512, T=150, dino=768, depth=1, precision='bf16', name='BASELINE configs[2] per GPU: B=64, 2048 support + 512 query, T=150, xyz+depth(1)+DINOv2-768'),
+    5: dict(B=8, N=8192, Q=2048, T=300, dino=768, depth=1, precision='fp16', name='BASELINE configs[4] per GPU: 8192 support + 2048 query, T=300, xyz+depth(1)+DINOv2-768, fp16 (per-GPU batch unspecified upstream)'),
 }
 
 # profile class -> (bound, kernel-name prefixes in the rocprofv3 summaries under profiles/)
@@ -49,6 +52,7 @@ CLASS_INFO = {
     'gemm_nt_bf16': ('mfma', ('gemm_nt',)), 'gemm_tn_bf16': ('mfma', ('gemm_tn',)), 'gemm_generic': ('mfma', ('gemm_generic',)),
     'attention_fused_fwd': ('hbm', ('attn_fwd', 'xattn_fwd', 'xattn_combine')), 'attention_fused_bwd': ('hbm', ('attn_bwd', 'xattn_dq_finish')),
     'layernorm_fwd': ('hbm', ('ln_fwd',)), 'layernorm_bwd': ('hbm', ('ln_bwd',)), 'attention_single_query': ('hbm', ('attn_q1',)),
+    'embed': ('hbm', ()),  # the input-streaming stage north_star wants at the HBM roofline: live timing only (its kernels are shared with other classes)
 }
 
 
@@ -84,16 +88,36 @@ def synth_batch(B, N, Q, T, dino_dim, depth_dim, device, seed, feat_dtype=torch.
   return batch
 
 
+def current_round():
+  """The round this tree is being built in = 1 + the newest BENCH_rNN.json the driver has left at the repo root."""
+  import re
+  done = [int(m.group(1)) for m in (re.match(r'BENCH_r(\d+)\.json$', f) for f in os.listdir(ROOT)) if m]
+  return (max(done) if done else 0) + 1
+
+
 def pmc_tables():
   """Per-kernel FETCH_SIZE / WRITE_SIZE totals of the committed rocprofv3 --pmc passes of this same command (separate passes, KiB
-  units; `tools/profile_round.sh`).  Newest round first."""
+  units; `tools/profile_round.sh`).  Newest round first.  Returns (rows, source, round tag, staleness warning or None)."""
   import csv
-  for tag in ('r03', 'r02', 'r01'):
+  import re
+  tags = sorted({m.group(1) for m in (re.match(r'(r\d+)_bench_b64_pmc_fetch\.csv$', f) for f in os.listdir(os.path.join(ROOT, 'profiles'))) if m}, reverse=True)
+  for tag in tags:
     f_fetch = os.path.join(ROOT, 'profiles', f'{tag}_bench_b64_pmc_fetch.csv'); f_write = os.path.join(ROOT, 'profiles', f'{tag}_bench_b64_pmc_write.csv')
     if os.path.exists(f_fetch) and os.path.exists(f_write):
       rows = list(csv.DictReader(open(f_fetch))) + list(csv.DictReader(open(f_write)))
-      return rows, f'profiles/{tag}_bench_b64_pmc_fetch.csv + _write.csv (rocprofv3 --pmc, bench.py --steps 1)'
-  return [], None
+      cur = current_round()
+      warn = None if int(tag[1:]) >= cur else f'PMC tables are from round {int(tag[1:])}, this tree is round {cur}: traffic figures describe an older build'
+      return rows, f'profiles/{tag}_bench_b64_pmc_fetch.csv + _write.csv (rocprofv3 --pmc, bench.py --steps 1)', tag, warn
+  return [], None, None, None
+
+
+def pmc_step_bytes(rows):
+  """HBM bytes of ONE whole step over EVERY kernel of the PMC passes: (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB / steps (same corrections as
+  pmc_traffic).  The step's real bound: it moves ~200 x the algorithmic minimum through HBM (activations of every op round-trip)."""
+  fetch = sum(float(r['total']) for r in rows if r['counter'] == 'FETCH_SIZE')
+  write = sum(float(r['total']) for r in rows if r['counter'] == 'WRITE_SIZE')
+  psteps = max([int(r['dispatches']) for r in rows if r['kernel'].startswith('adamw_kernel') and r['counter'] == 'FETCH_SIZE'] or [0])
+  return (2.0 * fetch + write) * 1024.0 / psteps if psteps and fetch + write > 0 else None
 
 
 def pmc_traffic(rows, prefixes):
@@ -120,7 +144,7 @@ def roofline_from_profile(spa3d, model, handle, steps, peak_flops, pmc=True):
   raw = spa3d.profile_summary(model, handle, peak_flops)
   if raw is None:
     return None
-  rows, src = pmc_tables() if pmc else ([], None)  # the committed PMC passes are of the headline workload only
+  rows, src, tag, warn = pmc_tables() if pmc else ([], None, None, None)  # the committed PMC passes are of the headline workload only
   classes = []
   for c in raw['classes']:
     key = c['kernel'].split(' ')[0]
@@ -143,10 +167,14 @@ def roofline_from_profile(spa3d, model, handle, steps, peak_flops, pmc=True):
     classes.append(e)
   if not classes:
     return None
-  dom = max(classes, key=lambda r: r['ms_per_step'])
+  dom = max((c for c in classes if not c['kernel'].startswith('embed')), key=lambda r: r['ms_per_step'])  # 'embed' overlaps the GEMM classes
   out = {k: dom[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launches', 'avg_launch_ms',
                              'algorithmic_bytes_per_launch', 'traffic_ratio')}
   out['traffic_source'] = src
+  out['traffic_round'] = tag
+  if warn:
+    out['traffic_warning'] = warn
+  out['hbm_bytes_per_step'] = pmc_step_bytes(rows) if rows else None
   out['classes'] = classes
   mfma_flops = sum(c['flops'] for c in raw['classes'] if CLASS_INFO.get(c['kernel'].split(' ')[0], ('mfma',))[0] == 'mfma')
   return out, mfma_flops
@@ -242,7 +270,7 @@ def main():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=3)
   ap.add_argument('--warmup', type=int, default=1)
-  ap.add_argument('--config', type=int, default=3, choices=(1, 2, 3), help='BASELINE.json configs[N-1] (default 3 = the headline C=772 workload)')
+  ap.add_argument('--config', type=int, default=3, choices=(1, 2, 3, 5), help='BASELINE.json configs[N-1] (default 3 = the headline C=772 workload; 5 = the fp16 stress shape)')
   ap.add_argument('--batch', type=int, default=None, help='per-GPU batch override (dev runs)')
   ap.add_argument('--support', type=int, default=None)
   ap.add_argument('--query', type=int, default=None)
@@ -279,7 +307,7 @@ def main():
   B = args.batch or int(os.environ.get('SPA3D_BENCH_B', cfg['B']))
   N, Q, T = args.support or cfg['N'], args.query or cfg['Q'], args.frames or cfg['T']
   dino, depth, precision = cfg['dino'], cfg['depth'], cfg['precision']
-  fdt = torch.bfloat16 if precision == 'bf16' else torch.float32
+  fdt = {'bf16': torch.bfloat16, 'fp16': torch.float16}.get(precision, torch.float32)
   model = spa3d.TrackAutoEncoder3D(num_output_frames=T, dino_feature_dim=max(dino, 1), depth_feature_dim=max(depth, 1), use_dino=dino > 0,
                                    use_depth=depth > 0, precision=precision, workspace_fraction=float(os.environ.get('SPA3D_WS_FRACTION', 0.80)))
   batch = synth_batch(B, N, Q, T, dino, depth, dev, seed=1234 + rank, feat_dtype=fdt)
@@ -304,7 +332,7 @@ def main():
     metrics = state.train_step(batch)
   sync()
   dt = time.perf_counter() - t0
-  peak = PEAK_BF16_FLOPS if precision == 'bf16' else PEAK_F32_FLOPS
+  peak = PEAK_BF16_FLOPS if precision in ('bf16', 'fp16') else PEAK_F32_FLOPS
   roof, mfma_flops = None, None
   if prof:
     r = roofline_from_profile(spa3d, model, h, args.steps, peak, pmc=(args.config == 3 and (B, N, Q, T) == (64, 2048, 512, 150)))
@@ -329,7 +357,7 @@ def main():
     out = {
         'metric': f'train-step tracks/sec (B x N_tracks) at T={T}, C={C}', 'value': tracks / dt, 'unit': 'tracks/s',
         'n_gpus': world, 'rccl_ranks': rccl_ranks, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if precision == 'bf16' else 'f32', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': {'bf16': 'bf16', 'fp16': 'f16'}.get(precision, 'f32'), 'data': 'synthetic',
         'config': {'workload': cfg['name'] + ', fwd+loss+bwd+clip+AdamW' + (f' [overrides: B={B}, N={N}, Q={Q}, T={T}]' if (B, N, Q, T) != (cfg['B'], cfg['N'], cfg['Q'], cfg['T']) else ''),
                    'baseline_config': args.config, 'per_gpu_batch': B, 'global_batch': B * world, 'support': N, 'query': Q,
                    'frames': T, 'channels': C, 'parallelism': f'dp{world}', 'chunk_samples': int(os.environ.get('SPA3D_CHUNK', 0)),
@@ -343,6 +371,9 @@ def main():
       out['step_mfma_frac_F_ref'] = (3 * F_REF_FWD_PER_STEP_B64[args.config] * scale / (ms / 1e3)) / peak  # reference graph, nothing pruned
     if mfma_flops:
       out['step_mfma_frac_executed'] = (mfma_flops / args.steps / (ms / 1e3)) / peak  # FLOPs the MFMA kernels actually ran (pruned last blocks)
+    if roof and roof.get('hbm_bytes_per_step'):  # whole-step HBM traffic (PMC, committed pass of this command) over this run's step time
+      out['hbm_bytes_per_step'] = roof['hbm_bytes_per_step']
+      out['step_hbm_frac'] = roof['hbm_bytes_per_step'] / (ms / 1e3) / PEAK_HBM
     if world == 1 and not args.no_cpu_baseline:
       cb = cpu_baseline()
       if args.config != 1:

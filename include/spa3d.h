@@ -123,8 +123,9 @@ int spa3d_decode(spa3d_handle h, const float* params, const spa3d_batch* b, cons
 int spa3d_forward(spa3d_handle h, const float* params, const spa3d_batch* b, spa3d_outputs* out,
                   void* ws, int64_t ws_bytes, void* stream);
 
-/* loss3 (device, >= 12 floats: [0..2] = total, position, visible; the rest is scratch).
- * denom<=0: use max(sum(visible),1) of this batch. */
+/* loss3 (device, >= 12 floats, 8-byte aligned: [0..2] = total, position, visible; the rest is scratch).
+ * denom<=0: use max(sum(visible),1) of this batch.  The batch sums are order-independent (64-bit fixed-point accumulation): the same
+ * inputs give the same bits on every run and on every data-parallel replica. */
 int spa3d_loss(spa3d_handle h, const spa3d_batch* b, const spa3d_outputs* preds, float denom,
                float* loss3, void* stream);
 
@@ -137,18 +138,31 @@ int spa3d_loss_and_grads(spa3d_handle h, const float* params, const spa3d_batch*
                          void* ws, int64_t ws_bytes, void* stream);
 
 /* clip_by_global_norm(clip) -> adamw(b1,b2,eps,wd) -> apply_updates on flat buffers, in place.
- * step = optimizer count BEFORE this update (bias correction uses step+1).
- * scratch: >= 4 KiB device, zero-initialised once by the caller and then left alone between steps: scratch[0] returns the global grad norm,
+ * step = number of spa3d_adamw_step calls BEFORE this one; the bias correction uses step + 1 - scratch[3] (updates actually applied:
+ * a skipped step leaves m and v untouched, so it does not count).
+ * The global norm is a fixed-order two-stage reduction (no float atomics): bit-identical gradients give bit-identical updates on every replica.
+ * scratch: >= 4 KiB device, zero-initialised once by the caller and then left alone between steps (floats [256, 768) are per-call partial sums;
+ * a multiplier in [4] that is not a power of two in [2^-24, 1] reads as 1): scratch[0] returns the global grad norm,
  * [1] is internal, [2] = 1 when THIS step was skipped because the norm was inf/NaN (an fp16 overflow; params, m, v unchanged) else 0,
  * [3] counts skipped steps, [4] / [5] hold the dynamic loss-scale multiplier and its good-step counter (spa3d_set_loss_scale_state). */
 int spa3d_adamw_step(float* params, const float* grads, float* m, float* v, int64_t n, float lr,
                      int64_t step, float clip, float b1, float b2, float eps, float wd,
                      float* scratch, void* stream);
 
-/* Per-handle switches (the same ones the SPA3D_* environment variables preset at spa3d_create): "prune" (token pruning of the track
- * encoder, 0/1), "ro_share" (shared latent rows of the first readout block, 0/1) -- with both 0 every entry point is fully asynchronous
- * (no plan count is read back) --, "loss_scale" (SPA3D_F16 handles: > 0 fixed, < 0 automatic with that head-gradient target),
- * "attn_bwd_mode", "attn_impl", "gemm_impl" (diagnostics).  Unknown names return SPA3D_ERR_ARG. */
+/* Per-handle switches -- the only ones the library has; each may be preset at spa3d_create from the environment variable of the same name in
+ * capitals with an SPA3D_ prefix (SPA3D_PRUNE ...).  Unknown names return SPA3D_ERR_ARG.
+ *   "prune"      0/1  token pruning of the track encoder (16-bit modes)            } with both 0 every entry point is fully asynchronous
+ *   "ro_share"   0/1  shared latent rows of the first readout block (16-bit modes) } (no plan count is read back)
+ *   "loss_scale"      SPA3D_F16 handles: > 0 fixed, < 0 automatic with that head-gradient target
+ *   "chunk"           samples processed at a time; 0 = as many as fit the workspace
+ *   "gemm_impl"       0 product dispatch | 1 generic strided MFMA kernel only | 2 tiled kernels | diagnostics that put small problems on the big
+ *                     kernels: 3 every eligible GEMM on the 8-phase kernels, 4 the same with the non-persistent 128x384 kernel, 5 without the
+ *                     single-buffer short-K kernel, 6 tiled GEMMs without the fused kernels (MLP forward as two GEMMs, multi-pass input embedding).  (The `impl` argument of spa3d_op_linear* takes
+ *                     the same values; spa3d_op_linear: | 16 = also write the pre-activation, the MLP-in form of the step.)
+ *   "attn_impl"       0 product dispatch | 1 generic composition | 2 fused kernels | 3, 4 fused with the split-pass backward on 4 / 8 waves (tests)
+ * and one test mode: "poison" 0/1 -- the workspace is filled with 16-bit NaN patterns before every sample chunk, so a read of a row that this
+ * call has not written (the rounded-up tails of pruned GEMMs, chunk-to-chunk reuse of the bump allocator) shows up as NaN instead of as a
+ * plausible stale value (tests/test_gpu_poison.py). */
 int spa3d_set_option(spa3d_handle h, const char* name, double value);
 
 /* Dynamic loss scaling of the SPA3D_F16 backward.  `state` (device, caller-owned, may be NULL to detach) is one float: a power-of-two
@@ -168,6 +182,15 @@ int spa3d_set_loss_scale_state(spa3d_handle h, const float* state);
  * on SPA3D_F16 handles (the loss-scaled buffer is rescaled as a whole at the end): use stream order there. */
 int spa3d_grad_segments(spa3d_handle h, int64_t* bounds4);
 int spa3d_set_grad_events(spa3d_handle h, void* ev_readout, void* ev_latents);
+/* out4 = {records of the readout event so far, records of the latents event so far, the registered ev_readout, the registered ev_latents}
+ * (host counters, bumped when a record is enqueued; the pointers as integers).  A caller about to wait on ITS events checks that they are
+ * still the registered ones and that both counters advanced during its last spa3d_loss_and_grads, and otherwise falls back to stream order: waiting on an event that was NOT re-recorded (another owner re-registered or detached the events, an SPA3D_F16 handle)
+ * would let the side-stream all-reduce start before the backward has produced the gradients. */
+int spa3d_grad_events_recorded(spa3d_handle h, int64_t* out4);
+/* Owner-aware detach: clears the registered events only if the handle still holds exactly (ev_readout, ev_latents), and the loss-scale
+ * state only if it still is `loss_scale_state`; NULL arguments are skipped.  Lets a train state that is being destroyed release what IT
+ * registered without tearing down what a newer state has registered on the same handle since. */
+int spa3d_detach(spa3d_handle h, void* ev_readout, void* ev_latents, const float* loss_scale_state);
 
 /* Data-dependent plan sizes of the last spa3d_loss_and_grads / forward call on this handle, summed over its sample chunks:
  * out4 = {track-encoder token rows kept, token rows before pruning, distinct (sample, query frame) slots, queries}; zeros when the
@@ -175,10 +198,14 @@ int spa3d_set_grad_events(spa3d_handle h, void* ev_readout, void* ev_latents);
 int spa3d_plan_stats(spa3d_handle h, double* out4);
 
 /* Live timing of the hot kernel classes with HIP event pairs recorded on the launch stream (bench.py's
- * "roofline" object).  cls: 0 tiled NT GEMM, 1 tiled TN GEMM (dW), 2 generic GEMM, 3 fused attention fwd,
- * 4 fused attention bwd.  out4 = {launches, total ms, algorithmic FLOPs, algorithmic bytes}. */
+ * "roofline" object).  cls: 0 tiled NT GEMM (incl. the fused MLP forward), 1 tiled TN GEMM (dW), 2 generic GEMM, 3 fused attention fwd,
+ * 4 fused attention bwd, 5 / 6 LayerNorm fwd / bwd, 7 single-query attention, 8 the input-embedding stage as a whole (its GEMMs are also
+ * counted in class 0).  out4 = {launches, total ms, algorithmic FLOPs, algorithmic bytes}. */
 int spa3d_prof_enable(spa3d_handle h, int32_t on);
 int spa3d_prof_read(spa3d_handle h, int32_t cls, double* out4);
+/* One CSV line per profiled launch group since spa3d_prof_enable(h, 1): class, ms, algorithmic FLOPs, algorithmic bytes, M, N, K, flags
+ * (tools/step_shapes.py aggregates it per GEMM shape).  Synchronises on the recorded events. */
+int spa3d_prof_dump(spa3d_handle h, const char* path);
 
 /* jax.random.uniform(PRNGKey(0),[n]) in the legacy (non-partitionable) threefry layout. */
 int spa3d_uniform_noise(float* out, int64_t n, uint32_t key0, uint32_t key1, void* stream);

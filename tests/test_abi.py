@@ -27,6 +27,11 @@ def test_library_exports_every_declared_symbol(spa3d):
   missing = [n for n in sorted(declared) if not hasattr(lib, n)]
   assert not missing, f'libspa3d_hip.so does not export: {missing}'
   assert declared == set(spa3d._lib.exported_symbols()), 'ctypes binding table and header disagree'
+  # and nothing undeclared leaks out of the library: its dynamic symbol table is exactly the header (the fp16 twins of the op entry points are hidden)
+  import subprocess
+  nm = subprocess.run(['nm', '-D', '--defined-only', spa3d._lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+  exported = {l.split()[-1] for l in nm.splitlines() if l.split()[-1].startswith('spa3d_')}
+  assert exported == declared, f'exported but not declared: {sorted(exported - declared)}; declared but not exported: {sorted(declared - exported)}'
   assert spa3d._lib.load().spa3d_version().startswith(b'spa3d-hip')
 
 

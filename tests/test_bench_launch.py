@@ -34,3 +34,22 @@ def test_world_size_mismatch_is_refused():
   r = _run(['--gpus', '4', '--launch-check'], env_extra={'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
   assert r.returncode == 2 and 'refusing' in r.stderr
   assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+
+
+def test_config5_argument_path_and_whole_step_hbm_fields():
+  """BASELINE.json configs[4] is reachable from the driver's command (`bench.py --config 5 [--batch B]`), and the whole-step HBM figure comes
+  from the committed PMC passes with their round tag (a warning field when they are older than the round this tree is built in)."""
+  sys.path.insert(0, ROOT)
+  import bench
+  c5 = bench.CONFIGS[5]
+  assert (c5['N'], c5['Q'], c5['T'], c5['dino'], c5['depth'], c5['precision']) == (8192, 2048, 300, 768, 1, 'fp16') and c5['B'] >= 1
+  r = _run(['--gpus', '1', '--config', '5', '--batch', '2', '--launch-check'])
+  assert r.returncode == 0, r.stderr[-2000:]
+  r = _run(['--gpus', '1', '--config', '4', '--launch-check'])
+  assert r.returncode != 0  # configs[3] is --gpus 8 of config 3, not a config of its own
+  rows, src, tag, warn = bench.pmc_tables()
+  assert rows and tag and src.startswith('profiles/' + tag)
+  by = bench.pmc_step_bytes(rows)
+  assert 1e12 < by < 2e13  # TB per step: the activations of every op round-trip through HBM
+  assert (warn is None) == (int(tag[1:]) >= bench.current_round())
+  assert 'embed' in bench.CLASS_INFO

@@ -26,28 +26,30 @@ CHILD = textwrap.dedent('''
   if world > 1:
     dist.init_process_group('gloo', rank=rank, world_size=world)
   cfg = O.Config(**MINI, use_dino=True, use_depth=True, dino_feature_dim=24, depth_feature_dim=1)
-  full = {k: v.cuda() for k, v in O.synthetic_batch(2, 10, 6, 8, seed=5, dino_dim=24, depth_dim=1).items()}
+  BT = int(os.environ.get('BATCH', '2')); bl = BT // world
+  full = {k: v.cuda() for k, v in O.synthetic_batch(BT, 10, 6, 8, seed=5, dino_dim=24, depth_dim=1).items()}
   full['query_tracks_visible'][0, :3] = 0   # unequal visible counts per shard: local denominators would be wrong
-  batch = {k: v[rank:rank + 1].contiguous() for k, v in full.items()} if world > 1 else full
+  batch = {k: v[rank * bl:(rank + 1) * bl].contiguous() for k, v in full.items()} if world > 1 else full
   model = product_model(spa3d, cfg, 'fp32')
   # deliberately different initial parameters per rank: the construction-time broadcast must make them rank 0's
   st = spa3d.TrainState(model, model.init(rank, full)['params'], learning_rate=1e-2, warmup_steps=1, total_steps=10, grad_bucket_bytes=4096)
   losses = []
-  for _ in range(2):
+  for _ in range(3):
     m = st.train_step(batch)
     losses.append(float(m['train/loss']))
   torch.cuda.synchronize()
-  if rank == 0:
-    torch.save({'flat': st.flat.cpu(), 'losses': losses, 'gn': float(m['train/grad_norm'])}, os.environ['OUT'])
+  # EVERY rank saves its replica: the test compares them bit for bit
+  torch.save({'flat': st.flat.cpu(), 'm': st.m.cpu(), 'losses': losses, 'gn': float(m['train/grad_norm']), 'overlap': st._overlap is not None},
+             os.environ['OUT'] + '.rank%%d' %% rank)
   if world > 1:
     dist.barrier(); dist.destroy_process_group()
 ''') % (ROOT, ROOT)
 
 
-def _launch(world, out, port):
+def _launch(world, out, port, **extra):
   procs = []
   for r in range(world):
-    env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OUT=out)
+    env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OUT=out, **extra)
     procs.append(subprocess.Popen([sys.executable, '-c', CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
   outs = []
   for p in procs:
@@ -59,19 +61,48 @@ def _launch(world, out, port):
   return outs
 
 
-def test_hip_trainstate_world2_equals_the_full_batch_step(tmp_path):
+def _port():
   import socket
-  import torch
   s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  return port
+
+
+def test_hip_trainstate_world2_equals_the_full_batch_step(tmp_path):
+  import torch
   o1, o2 = str(tmp_path / 'w1.pt'), str(tmp_path / 'w2.pt')
-  r1 = _launch(1, o1, port)
+  r1 = _launch(1, o1, _port())
   assert r1[0][0] == 0, r1[0][1][-3000:]
-  r2 = _launch(2, o2, port)
-  assert all(rc == 0 for rc, _ in r2), '\\n'.join(o[-2000:] for _, o in r2)
-  a, b = torch.load(o1, weights_only=True), torch.load(o2, weights_only=True)
+  r2 = _launch(2, o2, _port())
+  assert all(rc == 0 for rc, _ in r2), '\n'.join(o[-2000:] for _, o in r2)
+  a = torch.load(o1 + '.rank0', weights_only=True)
+  b, b1 = torch.load(o2 + '.rank0', weights_only=True), torch.load(o2 + '.rank1', weights_only=True)
+  # replicas are IDENTICAL after three steps: same reduced gradients, a fixed-order gradient norm (no float atomics) -> same clip, same update
+  assert torch.equal(b['flat'], b1['flat']) and torch.equal(b['m'], b1['m']) and b['losses'] == b1['losses'] and b['gn'] == b1['gn']
   diff = float((a['flat'] - b['flat']).abs().max())
   print('world 1 vs world 2: max |param diff|', diff, 'losses', a['losses'], b['losses'], 'grad norms', a['gn'], b['gn'])
-  assert diff < 2e-5   # two AdamW steps at lr 1e-2 on fp32 buffers; gradients differ by summation order only
+  assert diff < 3e-5   # three AdamW steps at lr 1e-2 on fp32 buffers; gradients differ by summation order only
   for x, y in zip(a['losses'], b['losses']):
     assert abs(x - y) <= 1e-5 * abs(x)
   assert abs(a['gn'] - b['gn']) <= 1e-4 * abs(a['gn'])
+
+
+def test_hip_trainstate_world2_several_chunks_overlap_on_and_off(tmp_path):
+  """B_local = 2 with SPA3D_CHUNK=1: two sample chunks per rank, so parameter gradients ACCUMULATE across chunks and the segment events of the
+  overlapped all-reduce (include/spa3d.h, spa3d_set_grad_events) must fire in the last chunk only.  Within a run both replicas are IDENTICAL;
+  overlap on and off are two runs, whose parameter gradients differ in the last bits (dW / broadcast-gradient sums use float atomics), and
+  both equal the single-process step on the whole batch."""
+  import torch
+  outs = {}
+  for tag, world, env in (('full', 1, {}), ('ov1', 2, {'SPA3D_DP_OVERLAP': '1'}), ('ov0', 2, {'SPA3D_DP_OVERLAP': '0'})):
+    o = str(tmp_path / (tag + '.pt'))
+    r = _launch(world, o, _port(), BATCH='4', SPA3D_CHUNK='1', **env)
+    assert all(rc == 0 for rc, _ in r), '\n'.join(x[-2000:] for _, x in r)
+    outs[tag] = [torch.load(o + '.rank%d' % k, weights_only=True) for k in range(world)]
+  assert outs['ov1'][0]['overlap'] and not outs['ov0'][0]['overlap']
+  for tag in ('ov1', 'ov0'):
+    assert torch.equal(outs[tag][0]['flat'], outs[tag][1]['flat']) and torch.equal(outs[tag][0]['m'], outs[tag][1]['m'])
+  d01 = float((outs['ov1'][0]['flat'] - outs['ov0'][0]['flat']).abs().max())
+  assert d01 < 1e-5 and all(abs(x - y) <= 1e-6 * abs(x) for x, y in zip(outs['ov1'][0]['losses'], outs['ov0'][0]['losses']))
+  diff = float((outs['full'][0]['flat'] - outs['ov1'][0]['flat']).abs().max())
+  print('4 samples as 2 ranks x 2 chunks vs one process x 4 chunks: max |param diff|', diff)
+  assert diff < 3e-5

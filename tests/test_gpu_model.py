@@ -262,7 +262,7 @@ def test_cfg1_bf16_tiled_vs_generic_and_fp32(spa3d, monkeypatch):
 
 @pytest.mark.gpu
 def test_cfg1_bf16_forced_8phase_kernels_vs_generic(spa3d, monkeypatch):
-  """Same graph with the 8-phase NT / TN kernels forced on for every eligible GEMM (SPA3D_NT_8P=2, SPA3D_TN_8P=2: small and
+  """Same graph with the 8-phase NT / TN kernels forced on for every eligible GEMM (SPA3D_GEMM_IMPL=4: small and
   ragged M, the row remaps of the pruned blocks, all tile configurations) against the generic kernels."""
   cfg = O.Config(num_output_frames=24, use_dino=True, use_depth=True, dino_feature_dim=768, depth_feature_dim=1)
   B, N, Q, T = 2, 64, 16, 24
@@ -271,17 +271,12 @@ def test_cfg1_bf16_forced_8phase_kernels_vs_generic(spa3d, monkeypatch):
   gb['dino_features'] = gb['dino_features'].bfloat16()
   gb['depth_features'] = gb['depth_features'].bfloat16()
   noise = _noise(B, cfg).cuda()
-  monkeypatch.setenv('SPA3D_NT_8P', '2')
-  monkeypatch.setenv('SPA3D_NT_8PP', '1')
-  monkeypatch.setenv('SPA3D_TN_8P', '2')
+  monkeypatch.setenv('SPA3D_GEMM_IMPL', '4')
   m_8p = product_model(spa3d, cfg, 'bf16')
   params = m_8p.init(0, gb)['params']
   _perturb(params)
   ld_f, g_f, p_f = m_8p.loss_and_grads({'params': params}, gb, noise=noise, return_predictions=True)
   g_fast = g_f.flat.clone()
-  monkeypatch.delenv('SPA3D_NT_8P')
-  monkeypatch.delenv('SPA3D_NT_8PP')
-  monkeypatch.delenv('SPA3D_TN_8P')
   monkeypatch.setenv('SPA3D_GEMM_IMPL', '1')
   monkeypatch.setenv('SPA3D_ATTN_IMPL', '1')
   m_gen = product_model(spa3d, cfg, 'bf16')

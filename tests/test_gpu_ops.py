@@ -241,7 +241,7 @@ def test_adamw_step_matches_oracle(lib):
 @pytest.mark.parametrize('M,N,K,act,res,bias', [(1000, 384, 256, 0, False, True), (4133, 2304, 384, 0, False, False),
                                                 (777, 1536, 384, 1, False, True), (2050, 384, 1536, 0, True, True),
                                                 (300, 600, 1280, 0, False, True), (129, 1280, 12352, 0, False, True)])
-def test_linear_tiled_nt(lib, M, N, K, act, res, bias):
+def test_linear_tiled_nt(lib, M, N, K, act, res, bias, impl=2):
   g = torch.Generator().manual_seed(11)
   A = torch.randn(M, K, generator=g).bfloat16()
   B = (torch.randn(K, N, generator=g) / math.sqrt(K)).bfloat16()
@@ -253,7 +253,7 @@ def test_linear_tiled_nt(lib, M, N, K, act, res, bias):
   Cd = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)
   ws = _ws()
   rc = lib.spa3d_op_linear(Ad.data_ptr(), Bd.data_ptr(), bd.data_ptr() if bias else None, Rd.data_ptr() if res else None, Cd.data_ptr(),
-                           M, N, K, act, BF16, 2, ws.data_ptr(), ws.numel(), _s())
+                           M, N, K, act, BF16, impl, ws.data_ptr(), ws.numel(), _s())
   assert rc == 0
   ref = A.double() @ B.double()
   if bias:
@@ -268,7 +268,7 @@ def test_linear_tiled_nt(lib, M, N, K, act, res, bias):
 
 
 @pytest.mark.parametrize('M,N,K', [(5000, 384, 256), (3333, 2304, 384), (20000, 128, 64), (1100, 600, 1280), (257, 96, 512)])
-def test_linear_bwd_tiled(lib, M, N, K):
+def test_linear_bwd_tiled(lib, M, N, K, impl=2):
   """dA = dC.B^T on the NT kernel (needs N % 64 == 0, else generic), dB = A^T.dC on the transposed-read TN kernel."""
   g = torch.Generator().manual_seed(12)
   A = torch.randn(M, K, generator=g).bfloat16()
@@ -278,11 +278,11 @@ def test_linear_bwd_tiled(lib, M, N, K):
   dA = torch.full((M, K), float('nan'), device='cuda', dtype=torch.bfloat16)
   dB = torch.full((K, N), float('nan'), device='cuda')
   ws = _ws()
-  impl_a = 2 if (N % 64 == 0 and M * K >= 128 * 128) else 0
+  impl_a = impl if (N % 64 == 0 and M * K >= 128 * 128) else 0
   rc = lib.spa3d_op_linear_bwd(Ad.data_ptr(), Bd.data_ptr(), dCd.data_ptr(), dA.data_ptr(), None, None, M, N, K, BF16, impl_a,
                                ws.data_ptr(), ws.numel(), _s())
   assert rc == 0
-  rc = lib.spa3d_op_linear_bwd(Ad.data_ptr(), Bd.data_ptr(), dCd.data_ptr(), None, dB.data_ptr(), None, M, N, K, BF16, 2,
+  rc = lib.spa3d_op_linear_bwd(Ad.data_ptr(), Bd.data_ptr(), dCd.data_ptr(), None, dB.data_ptr(), None, M, N, K, BF16, impl,
                                ws.data_ptr(), ws.numel(), _s())
   assert rc == 0
   assert rel_err(dA.float(), dC.double() @ B.double().T) < 4e-3
@@ -293,23 +293,21 @@ def test_linear_bwd_tiled(lib, M, N, K):
 
 @pytest.mark.parametrize('M,N,K', [(5000, 384, 256), (3333, 2304, 384), (20000, 128, 64), (1100, 600, 1280), (257, 96, 512),
                                    (9000, 768, 1280), (70001, 384, 768), (4097, 1536, 384), (640, 1280, 1536)])
-def test_linear_bwd_tiled_8phase(lib, monkeypatch, M, N, K):
-  """dB = A^T.dC on the 8-phase TN kernels (256x256 / 128x384 / 384x128 tiles, ring of 16-row quarters), forced for any M"""
-  monkeypatch.setenv('SPA3D_TN_8P', '2')
-  monkeypatch.setenv('SPA3D_NT_8P', '2')
-  test_linear_bwd_tiled(lib, M, N, K)
+def test_linear_bwd_tiled_8phase(lib, M, N, K):
+  """dB = A^T.dC on the 8-phase TN kernels (256x256 / 128x384 / 384x128 tiles, ring of 16-row quarters), forced for any M (impl 3)"""
+  test_linear_bwd_tiled(lib, M, N, K, impl=3)
 
 
-@pytest.mark.parametrize('bwd_mode', ['1', '2', '3', '4', '5'])
+@pytest.mark.parametrize('bwd_mode', ['1', '2', '3'])
 @pytest.mark.parametrize('nseq,S,H,masked', [(5, 25, 8, True), (3, 129, 8, False), (4, 151, 8, True), (2, 128, 8, False), (3, 40, 2, True),
                                              (17, 151, 8, True), (3, 301, 8, True), (2, 200, 8, False), (2, 320, 4, True), (9, 193, 2, True), (3, 176, 8, True), (2, 160, 4, False)])
-def test_attention_fused_fwd_bwd(lib, monkeypatch, nseq, S, H, masked, bwd_mode):
+def test_attention_fused_fwd_bwd(lib, nseq, S, H, masked, bwd_mode):
   """LDS-resident fused forward / backward (impl=2) vs the fp64 oracle; packed q|k|v rows as the QKV projection writes them.
-  bwd_mode: 1 = four resident images + concurrent roles (S <= 160), 2 / 3 = split-pass with 4 / 8 waves, 4 / 5 = single orientation + dS hand-off
-  through LDS with 8 / 12 waves (S <= 160; round 3, opt-in); S > 160 (BASELINE cfg#5: S = 301) always takes the 8-wave split-pass kernel.  nseq = 17 / 9 exercise the XCD-major problem map's identity tail."""
+  bwd_mode: 1 = four resident images + concurrent roles (S <= 160; the product dispatch, impl 2), 2 / 3 = split-pass with 4 / 8 waves (impl 3 / 4);
+  S > 160 (BASELINE cfg#5: S = 301) always takes the 8-wave split-pass kernel.  nseq = 17 / 9 exercise the XCD-major problem map's identity tail."""
   if S > 160 and bwd_mode != '3':
     pytest.skip('S > 160 has one backward structure')
-  monkeypatch.setenv('SPA3D_ATTN_BWD_MODE', bwd_mode)
+  bwd_impl = {'1': 2, '2': 3, '3': 4}[bwd_mode]
   Dh, E = 96, H * 96
   g = torch.Generator().manual_seed(21)
   qkv = torch.randn(nseq, S, 3 * E, generator=g).bfloat16()
@@ -349,7 +347,7 @@ def test_attention_fused_fwd_bwd(lib, monkeypatch, nseq, S, H, masked, bwd_mode)
   rc = lib.spa3d_op_attention_bwd(qkvd[..., :E].data_ptr(), qkvd[..., E:2 * E].data_ptr(), qkvd[..., 2 * E:].data_ptr(), 3 * E, 3 * E,
                                   3 * E, sqd.data_ptr(), skd.data_ptr(), kmd.data_ptr() if masked else None, nseq, S, S, H, Dh,
                                   o.data_ptr(), lse.data_ptr(), dod.data_ptr(), dqkv[..., :E].data_ptr(), dqkv[..., E:2 * E].data_ptr(),
-                                  dqkv[..., 2 * E:].data_ptr(), dsq.data_ptr(), dsk.data_ptr(), BF16, 2, ws.data_ptr(), ws.numel(), _s())
+                                  dqkv[..., 2 * E:].data_ptr(), dsq.data_ptr(), dsk.data_ptr(), BF16, bwd_impl, ws.data_ptr(), ws.numel(), _s())
   assert rc == 0
   assert not torch.isnan(dqkv.float()).any()
   errs = [rel_err(dqkv[..., :E].float(), qr.grad), rel_err(dqkv[..., E:2 * E].float(), kr.grad), rel_err(dqkv[..., 2 * E:].float(), vr.grad),
@@ -418,10 +416,9 @@ def test_attention_fused_cross(lib, dtype, nseq, Sq, Sk, H, masked):
 
 
 @pytest.mark.parametrize('M,N,K,act,res,bias', [(1000, 384, 256, 0, False, True), (4133, 2304, 384, 0, False, False), (2050, 384, 1536, 0, True, True)])
-def test_linear_tiled_nt_double_buffered(lib, monkeypatch, M, N, K, act, res, bias):
-  """the 2-buffer kernel with the LDS-staged epilogue also on the short-K shapes the single-buffer kernel normally takes"""
-  monkeypatch.setenv('SPA3D_NT_OCC', '0')
-  test_linear_tiled_nt(lib, M, N, K, act, res, bias)
+def test_linear_tiled_nt_double_buffered(lib, M, N, K, act, res, bias):
+  """the 2-buffer kernel with the LDS-staged epilogue also on the short-K shapes the single-buffer kernel normally takes (impl 5)"""
+  test_linear_tiled_nt(lib, M, N, K, act, res, bias, impl=5)
 
 
 @pytest.mark.parametrize('M,N,K,act,res,bias', [(4133, 2304, 384, 0, False, False), (1000, 1536, 384, 1, False, True),
@@ -429,32 +426,21 @@ def test_linear_tiled_nt_double_buffered(lib, monkeypatch, M, N, K, act, res, bi
                                                 (513, 512, 128, 0, False, True), (256, 256, 192, 0, True, False), (9000, 1280, 768, 0, True, True),
                                                 (4133, 384, 768, 0, True, True), (900, 1152, 256, 1, False, True), (130, 384, 64, 0, False, False),
                                                 (2050, 384, 1536, 0, True, True), (777, 384, 128, 0, False, True)])
-def test_linear_tiled_nt_8phase(lib, monkeypatch, M, N, K, act, res, bias):
-  """the 8-phase kernels (256x256 when 256 | N, 128x384 when 384 | N; counted vmcnt, staggered wave rows), forced on for any M with SPA3D_NT_8P=2;
+def test_linear_tiled_nt_8phase(lib, M, N, K, act, res, bias):
+  """the 8-phase kernels (256x256 when 256 | N, 128x384 when 384 | N; counted vmcnt, staggered wave rows), forced on for any M (impl 4: the 128x384
+  shapes on the NON-persistent kernel; the persistent one is the default since round 3);
   K = 64 / 128 / 192 exercise the prologue and tail paths of the schedule (1, 2, 3 K-tiles)"""
-  monkeypatch.setenv('SPA3D_NT_8P', '2')
-  monkeypatch.setenv('SPA3D_NT_8PP', '1')  # (the 128x384 shapes on the NON-persistent kernel: the persistent one is the default since round 3)
-  test_linear_tiled_nt(lib, M, N, K, act, res, bias)
-
-
-@pytest.mark.parametrize('M,N,K,act,res,bias', [(256, 256, 128, 0, False, True), (513, 512, 384, 1, True, True), (1024, 2304, 384, 0, False, False),
-                                                (1500, 1280, 768, 0, True, True), (777, 768, 64, 0, False, True), (130, 128, 128, 0, False, True), (4133, 1536, 192, 1, False, True)])
-def test_linear_tiled_nt_8phase_two_workgroups_per_cu(lib, monkeypatch, M, N, K, act, res, bias):
-  """the 8-phase schedule at 128 x 128 tiles, two workgroups per CU (SPA3D_NT_8P=42: the round-3 store-drain-overlap experiment, opt-in, rejected by measurement)"""
-  monkeypatch.setenv('SPA3D_NT_8P', '42')
-  test_linear_tiled_nt(lib, M, N, K, act, res, bias)
+  test_linear_tiled_nt(lib, M, N, K, act, res, bias, impl=4)
 
 
 @pytest.mark.parametrize('M,N,K,act,res,bias', [(70001, 512, 256, 0, True, True), (70008, 512, 256, 0, True, True), (140000, 256, 128, 1, False, True), (66000, 768, 384, 0, False, False),
                                                 (4133, 2304, 384, 0, True, False), (256 * 300, 512, 192, 0, True, True), (9000, 1280, 768, 1, False, True),
                                                 (70008, 384, 256, 0, True, True), (66000, 1152, 384, 1, False, True), (140000, 384, 128, 0, False, False),
                                                 (65544, 384, 768, 0, True, False), (128 * 700, 384, 1536, 0, False, True)])
-def test_linear_tiled_nt_8phase_persistent(lib, monkeypatch, M, N, K, act, res, bias):
-  """persistent 8-phase kernels (256x256 and 128x384, SPA3D_NT_8PP=1): more tiles than CUs (cross-tile prefetch + counted store wait), ragged
+def test_linear_tiled_nt_8phase_persistent(lib, M, N, K, act, res, bias):
+  """persistent 8-phase kernels (256x256 and 128x384; impl 3): more tiles than CUs (cross-tile prefetch + counted store wait), ragged
   last M tile (drain path), exact multiples, residual / GELU epilogues"""
-  monkeypatch.setenv('SPA3D_NT_8P', '2')
-  monkeypatch.setenv('SPA3D_NT_8PP', '5')  # 5 = also the (opt-in) persistent 128x384 kernel
-  test_linear_tiled_nt(lib, M, N, K, act, res, bias)
+  test_linear_tiled_nt(lib, M, N, K, act, res, bias, impl=3)
 
 
 @pytest.mark.parametrize('dtype,impl', [(F32, 1), (BF16, 1), (BF16, 2)])

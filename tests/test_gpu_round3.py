@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import O, batch_to, product_model, rel_err
+from util import Gates, O, batch_to, product_model, rel_err
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -51,8 +51,11 @@ def test_full_width_sample_bf16_default_dispatch_vs_fp32_parity_mode(monkeypatch
   assert 0.85 < stats[0] / stats[1] < 0.95 and 0.2 < stats[2] / stats[3] < 0.45  # the pruned and shared paths ran, at the bench's data distribution
   e_t, e_v = rel_err(t16, t32), rel_err(v16, v32)
   print(f'full width bf16 vs fp32: tracks rel {e_t:.3e} logits rel {e_v:.3e} losses {l16} vs {l32}')
-  assert e_t < 2e-2 and e_v < 5e-2
-  assert abs(l16[0] - l32[0]) < 5e-3 * abs(l32[0]) and abs(l16[1] - l32[1]) < 5e-3 * abs(l32[1])
+  gt = Gates('full-width chunked batch, bf16 default dispatch vs the fp32 parity mode')
+  gt.le('tracks, relative Frobenius', e_t, 1.25e-2, '8.0e-3 ... 8.1e-3')
+  gt.le('visible logits, relative Frobenius', e_v, 1.3e-2, '8.4e-3 ... 8.5e-3')
+  gt.le('total loss, relative', abs(l16[0] - l32[0]) / abs(l32[0]), 1.8e-4, '5e-5 ... 1.2e-4')
+  gt.le('position loss, relative', abs(l16[1] - l32[1]) / abs(l32[1]), 1.8e-4, '5e-5 ... 1.2e-4')
   names = sorted(g32)
   worst = ('', 0.0)
   for k in names:
@@ -60,12 +63,13 @@ def test_full_width_sample_bf16_default_dispatch_vs_fp32_parity_mode(monkeypatch
     e = rel_err(g16[k], g32[k]) if n32 > 1e-12 else float(g16[k].abs().max())
     if e > worst[1]:
       worst = (k, e)
-    assert e < 0.20, (k, e)
     assert bool(torch.isfinite(g16[k]).all())
   a = torch.cat([g16[k].double().reshape(-1) for k in names]); b_ = torch.cat([g32[k].double().reshape(-1) for k in names])
   cos = float((a @ b_) / (a.norm() * b_.norm()))
   print(f'full width: worst bf16-vs-fp32 gradient leaf {worst}, whole-gradient cosine {cos:.5f}')
-  assert cos > 0.999
+  gt.le('worst gradient leaf, bf16 vs fp32, relative', worst[1], 0.15, '7.4e-2 ... 9.9e-2')
+  gt.le('1 - cosine(whole gradient)', 1.0 - cos, 9e-5, '6e-5')
+  gt.check()
 
 
 def _small_full_model_case(B=2, N=8, Q=16, T=24, seed=31):
@@ -178,69 +182,46 @@ def test_16bit_gradients_agree_with_fp32_along_the_fp32_trajectory(precision):
     st.train_step(b32, noise=noise)
   print(f'{precision} vs fp32 gradients over 30 fp32 states: cosine first 10 min {min(cosines[:10]):.6f}, overall min {min(cosines):.6f} at state {int(np.argmin(cosines))}; '
         f'worst significant leaf {worst}')
+  gt = Gates(f'{precision} gradients vs fp32 gradients at 30 states of an fp32 training run (the states themselves move in the last bits run to run)')
   if precision == 'bf16':
-    assert min(cosines[:10]) >= 0.999 and min(cosines) >= 0.995
-    assert worst[0] <= 0.25, worst
+    gt.le('1 - cosine, worst of the first 10 states', 1.0 - min(cosines[:10]), 1.6e-3, '6.6e-4 ... 1.04e-3 (three runs)')
+    gt.le('1 - cosine, worst of all 30 states', 1.0 - min(cosines), 5e-3, '3.2e-3 ... 3.9e-3')
+    gt.le('worst leaf holding >= 1 % of the norm, relative', worst[0], 0.25, '0.19 ... 0.21')
   else:
-    assert min(cosines) >= 0.999   # measured min 0.99946: (1 - cos) six times smaller than bf16's
-    assert worst[0] <= 0.10, worst
+    gt.le('1 - cosine, worst of all 30 states', 1.0 - min(cosines), 1e-3, '5.2e-4 ... 7.9e-4: (1 - cos) five times smaller than bf16')
+    gt.le('worst leaf holding >= 1 % of the norm, relative', worst[0], 0.125, '8.1e-2 ... 9.4e-2')
+  gt.check()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode', [4, 5])
-def test_single_orientation_attention_backward_in_model_ragged(mode):
-  """The opt-in single-orientation attention backward (attn_bwd_mode 4: 8 waves, 5: 12 waves) inside the full-size model on RAGGED sequences (token
-  pruning: case c772 has boundary_frame = (150, 97) and 10 % occlusion, so sequence lengths differ and whole key tiles past a sequence's end must
-  read as zeros in the dS image) against the default two-role kernel: every gradient leaf, fp16 (the sharp statement, as in
-  test_token_pruning_equals_the_dense_encoder)."""
+@pytest.mark.parametrize('mode', [3, 4])
+def test_split_pass_attention_backward_in_model_ragged_and_bit_reproducible_loss(mode):
+  """The split-pass attention backward (attn_impl 3: 4 waves, 4: 8 waves -- the S > 160 structure forced at S = 151) inside the full-size model on
+  RAGGED sequences (token pruning: case c772 has boundary_frame = (150, 97) and 10 % occlusion, so sequence lengths differ) against the default
+  two-role kernel: every gradient leaf, fp16.  The forward is the same code in both runs, so the loss must be BIT-IDENTICAL: the batch sums are
+  order-independent fixed-point accumulations (round 3 had float atomics here and 14089.21875 vs 14089.216796875 between two runs)."""
   import spa3d
   sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
   import make_t150_golden as G
   cfg, p, batch, noise = G.make_inputs('c772')
   lib = spa3d._lib.load()
   runs = {}
-  for m in (1, mode):
+  for m in (2, mode):
     model = product_model(spa3d, cfg, 'fp16')
     gb = batch_to(batch, 'cuda')
     for k in ('dino_features', 'depth_features'):
       gb[k] = gb[k].half()
     gp = O.tree_map(lambda t: t.cuda(), p)
     h = model._handle(768, 1)[0]
-    spa3d._lib.check(lib.spa3d_set_option(h, b'attn_bwd_mode', float(m)), h)
+    spa3d._lib.check(lib.spa3d_set_option(h, b'attn_impl', float(m)), h)
     ld, grads, preds = model.loss_and_grads({'params': gp}, gb, noise=noise.cuda(), return_predictions=True)
     torch.cuda.synchronize()
     runs[m] = (float(ld['total_loss']), {k: v.clone() for k, v in O.tree_flatten(grads).items()})
-  (l1, g1), (l4, g4) = runs[1], runs[mode]
+  (l1, g1), (l4, g4) = runs[2], runs[mode]
   worst = max((rel_err(g4[k], g1[k]), k) for k in g1 if float(g1[k].double().norm()) > 1e-12)
-  print(f'attention backward mode {mode} vs 1 in-model (ragged, fp16): loss {l4} vs {l1}; worst gradient leaf {worst}')
-  assert abs(l4 - l1) <= 1e-6 * abs(l1)  # the forward is the same code (the loss sums are float atomics: last-bit differences run to run)
+  print(f'attention impl {mode} (split-pass backward) vs 2 in-model (ragged, fp16): loss {l4} vs {l1}; worst gradient leaf {worst}')
+  assert l4 == l1  # the forward is the same code, and the loss sums are order-independent fixed-point accumulations (kernels.hip loss_acc_add)
   assert all(bool(torch.isfinite(v).all()) for v in g4.values())
   assert worst[0] < 0.04
 
 
-@pytest.mark.gpu
-def test_layernorm_folded_into_the_gemm_epilogue_equals_the_separate_kernel(monkeypatch):
-  """LayerNorm 2 of the track-encoder blocks (attention.py:103-105) computed in the epilogue of the out-projection GEMM (128 x 384 tiles own whole
-  rows; SPA3D_LN_FOLD, default on) against the stand-alone LayerNorm kernel, in-model at M >= 16 384 rows (case c772_tiles: the default dispatch takes
-  the 8-phase kernels).  Both normalise the same 16-bit-rounded values; only the summation order of the row statistics differs."""
-  import spa3d
-  sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
-  import make_t150_golden as G
-  cfg, p, batch, noise = G.make_inputs('c772_tiles')
-  runs = {}
-  for fold in ('1', '0'):
-    monkeypatch.setenv('SPA3D_LN_FOLD', fold)
-    model = product_model(spa3d, cfg, 'bf16')
-    gb = batch_to(batch, 'cuda')
-    for k in ('dino_features', 'depth_features'):
-      gb[k] = gb[k].bfloat16()
-    gp = O.tree_map(lambda t: t.cuda(), p)
-    ld, grads, preds = model.loss_and_grads({'params': gp}, gb, noise=noise.cuda(), return_predictions=True)
-    lat = model.apply({'params': gp}, gb, method=model.encode)
-    torch.cuda.synchronize()
-    runs[fold] = (float(ld['total_loss']), {k: v.clone() for k, v in O.tree_flatten(grads).items()}, preds.tracks.clone(), lat.clone())
-  (l1, g1, t1, e1), (l0, g0, t0, e0) = runs['1'], runs['0']
-  worst = max((rel_err(g1[k], g0[k]), k) for k in g0 if float(g0[k].double().norm()) > 1e-12)
-  print(f'LayerNorm folded vs separate: latents rel {rel_err(e1, e0):.3e} tracks rel {rel_err(t1, t0):.3e} loss {l1} vs {l0}; worst gradient leaf {worst}')
-  assert rel_err(e1, e0) < 5e-3 and rel_err(t1, t0) < 5e-3 and abs(l1 - l0) < 1e-3 * abs(l0)
-  assert worst[0] < 0.12  # two bf16 runs that differ in the last bit of a few row statistics (cf. pruned vs dense: 0.19)

@@ -12,9 +12,10 @@ regenerated from seeds on both sides and verified by checksum before anything is
 Tolerances:
   fp32 mode : tracks / logits / latents max-abs <= 1e-4 (north_star), losses relative 2e-5, EVERY gradient leaf's norm
               within 5e-3 relative of the oracle's and the stored whole leaves <= 5e-3 relative Frobenius error.
-  bf16 mode : (what the benchmark runs) compared DIRECTLY with the fp64 oracle: tracks / latents relative Frobenius <= 2e-2
-              (measured 7-9e-3), losses relative 5e-3 (measured ~2e-4), every leaf's norm within 12 % (measured <= 5 %; bf16
-              activations through 11 blocks), stored leaves <= 0.18 relative error (measured <= 8 %).  The `c772_tiles` case (M >= 16 384 rows, so
+  bf16 mode : (what the benchmark runs) compared DIRECTLY with the fp64 oracle, every bound <= 1.5 x the round-4 measurement (util.Gates prints
+              measured vs bound): tracks relative Frobenius <= 1.4e-2 (measured 7.4-9.2e-3), latents <= 1.1e-2 (6.8-7.4e-3), total / position loss
+              relative <= 6.5e-4 (1e-5 ... 4.1e-4), every leaf's norm within 7.5 % (1.7-4.9 %; bf16 activations through 11 blocks), stored leaves
+              <= 0.13 relative error (3.6-8.6 %).  The `c772_tiles` case (M >= 16 384 rows, so
               the default dispatch takes the 8-phase / persistent kernels bench.py runs on) additionally compares every bf16
               gradient leaf with the library's own fp32 path.
 """
@@ -25,7 +26,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import O, batch_to, max_abs, product_model, rel_err
+from util import Gates, O, batch_to, max_abs, product_model, rel_err
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
 import make_t150_golden as G  # noqa: E402  (input recipe + case table only; nothing numeric runs from it on the GPU box)
@@ -117,12 +118,15 @@ def test_t150_bf16_vs_oracle_golden(case):
   e_l = rel_err(lat, torch.from_numpy(exp['latents']))
   got = [float(ld[k]) for k in ('total_loss', 'position_loss', 'visible_loss')]
   print(f'{case} bf16 T=150: tracks rel {e_t:.3e} latents rel {e_l:.3e} losses {got} vs {exp["losses"].tolist()}')
-  assert e_t < 2e-2 and e_l < 2e-2          # measured 7-9e-3
-  assert abs(got[0] - exp['losses'][0]) < 5e-3 * abs(exp['losses'][0])   # measured 1.3-2.7e-4
-  assert abs(got[1] - exp['losses'][1]) < 5e-3 * abs(exp['losses'][1])
   names, rel, leaf = _leaf_report(gf, exp, f'{case} bf16')
-  assert float(rel.max()) < 0.12            # measured 4-5e-2
-  assert max(leaf.values()) < 0.18          # measured 6-8e-2
+  gt = Gates(f'{case} bf16 vs the fp64 oracle golden')
+  gt.le('tracks, relative Frobenius', e_t, 1.4e-2, '7.4e-3 ... 9.2e-3 over the four cases')
+  gt.le('latents, relative Frobenius', e_l, 1.1e-2, '6.8e-3 ... 7.4e-3')
+  gt.le('total loss, relative', abs(got[0] - exp['losses'][0]) / abs(exp['losses'][0]), 6.5e-4, '1e-5 ... 4.1e-4')
+  gt.le('position loss, relative', abs(got[1] - exp['losses'][1]) / abs(exp['losses'][1]), 6.5e-4, '1e-5 ... 4.1e-4')
+  gt.le('worst gradient-leaf norm, relative', float(rel.max()), 7.5e-2, '1.7e-2 ... 4.9e-2')
+  gt.le('worst stored gradient leaf, relative', max(leaf.values()), 0.13, '3.6e-2 ... 8.6e-2')
+  gt.check()
   assert all(bool(torch.isfinite(gf[k]).all()) for k in names)
 
 
@@ -147,10 +151,12 @@ def test_t150_tiles_default_dispatch_bf16_and_fp32():
   e_b = rel_err(preds.tracks, torch.from_numpy(exp['tracks']))
   got = [float(ld[k]) for k in ('total_loss', 'position_loss', 'visible_loss')]
   print(f'{case} bf16: tracks rel {e_b:.3e} losses {got} vs {exp["losses"].tolist()}')
-  assert e_b < 2e-2
-  assert abs(got[0] - exp['losses'][0]) < 5e-3 * abs(exp['losses'][0])
   names, rel, leaf = _leaf_report(gf, exp, f'{case} bf16')
-  assert float(rel.max()) < 0.05 and max(leaf.values()) < 0.15   # measured 1.3e-2 / 5.0e-2
+  gt = Gates(f'{case} bf16 (default dispatch: 8-phase / persistent / fused kernels) vs the fp64 oracle golden and vs the fp32 mode')
+  gt.le('tracks, relative Frobenius', e_b, 1.1e-2, '7.3e-3')
+  gt.le('total loss, relative', abs(got[0] - exp['losses'][0]) / abs(exp['losses'][0]), 6.5e-4, '3.0e-4')
+  gt.le('worst gradient-leaf norm, relative', float(rel.max()), 1.7e-2, '0.9e-2 ... 1.1e-2')
+  gt.le('worst stored gradient leaf, relative', max(leaf.values()), 7.4e-2, '4.4e-2 ... 4.9e-2')
   # per leaf, bf16 default kernels vs the fp32 path of the same library
   worst = ('', 0.0)
   for k in names:
@@ -158,11 +164,12 @@ def test_t150_tiles_default_dispatch_bf16_and_fp32():
     e = rel_err(gf[k], g32[k]) if n32 > 1e-12 else float(gf[k].abs().max())
     if e > worst[1]:
       worst = (k, e)
-    assert e < 0.20, (k, e)   # measured worst 7.9e-2
   a = torch.cat([gf[k].double().reshape(-1) for k in names]); b = torch.cat([g32[k].double().reshape(-1) for k in names])
   cos = float((a @ b) / (a.norm() * b.norm()))
   print(f'{case}: worst bf16-vs-fp32 leaf {worst}, whole-gradient cosine {cos:.5f}')
-  assert cos > 0.999  # measured 0.99989
+  gt.le('worst leaf, bf16 vs fp32 mode, relative', worst[1], 0.15, '7.1e-2 ... 9.9e-2')
+  gt.le('1 - cosine(whole gradient, bf16 vs fp32)', 1.0 - cos, 1.7e-4, '1.0e-4 ... 1.1e-4')
+  gt.check()
 
 
 @pytest.mark.gpu

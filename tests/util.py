@@ -50,3 +50,26 @@ def max_abs(a, b):
 def rel_err(a, b):
   a, b = a.double().cpu(), b.double().cpu()
   return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+class Gates:
+  """Accuracy gates of the 16-bit modes: every bound is <= 1.5 x the value measured in round 4 (profiles/r04_accuracy_gates.log), so a
+  2x accuracy regression FAILS instead of passing under a generous tolerance; one measured-vs-bound table is printed per test.
+  (1e-4 is a property of the fp32 parity mode only -- tests/test_gpu_t150.py::test_t150_fp32_vs_oracle_golden; the throughput number is bf16.)"""
+
+  def __init__(self, title):
+    self.title, self.rows = title, []
+
+  def le(self, name, value, bound, measured):
+    self.rows.append((name, float(value), float(bound), measured, float(value) <= float(bound)))
+
+  def ge(self, name, value, bound, measured):
+    self.rows.append((name, float(value), float(bound), measured, float(value) >= float(bound)))
+
+  def check(self):
+    print(f'  gates: {self.title}')
+    print(f'    {"quantity":44s} {"this run":>11s} {"bound":>11s}   measured in round 4')
+    for n, v, b, m, ok in self.rows:
+      print(f'    {n:44s} {v:11.4e} {b:11.4e}   {m}{"" if ok else "   <-- FAILED"}')
+    bad = [r[0] for r in self.rows if not r[4]]
+    assert not bad, f'{self.title}: gates failed: {bad}'

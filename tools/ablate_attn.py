@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import importlib
 b = importlib.import_module('3dspa_code_amd.build')
 out = os.path.join(ROOT, 'tools', '_ablate'); os.makedirs(out, exist_ok=True)
-MODE4 = os.environ.get('SPA3D_ATTN_BWD_MODE') in ('4', '5')
+MODE4 = False  # (the single-orientation kernel these masks ablated moved to tools/experiments/ in round 4)
 lib_path = os.path.join(out, 'libspa3d_ablate.so')
 if not os.environ.get('ABL1_CHILD'):
   b.build(verbose=False)

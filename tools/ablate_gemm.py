@@ -35,7 +35,7 @@ for (N, K, act, res) in ((2304, 384, 0, False), (1536, 384, 0, True), (768, 384,
   f = lambda: lib.spa3d_op_linear(A.data_ptr(), B.data_ptr(), None, R.data_ptr() if res else None, Cc.data_ptr(), Mm, N, K, act, 1, 2, ws.data_ptr(), ws.numel(), s())
   for pp in ('1',):
     for abl in ('0', '1'):
-      os.environ['SPA3D_NT_8PP'] = pp; os.environ['SPA3D_ABLATE'] = abl
+      os.environ['SPA3D_ABLATE'] = abl
       assert f() == 0
       ms = timeit(f)
       print(f'M={Mm:8d} N={N:5d} K={K:5d} aux={int(res)} tile={"256x256" if pp == "1" else "128x256"} stores={"off" if abl == "1" else "on "} {ms:8.3f} ms {2*Mm*N*K/ms/1e9:8.1f} TF/s', flush=True)

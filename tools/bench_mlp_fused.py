@@ -24,9 +24,8 @@ def fused():
 
 
 def pair():
-  os.environ['SPA3D_OP_PREOUT'] = '1'  # MLP-in with its second (pre-activation) output stream, as in the step
-  assert lib.spa3d_op_linear(na.data_ptr(), w_in.data_ptr(), b_in.data_ptr(), None, h.data_ptr(), M, mlp, d, 1, 1, 2, ws.data_ptr(), ws.numel(), s()) == 0
-  del os.environ['SPA3D_OP_PREOUT']
+  # impl 2 | 16: MLP-in with its second (pre-activation) output stream, as in the step
+  assert lib.spa3d_op_linear(na.data_ptr(), w_in.data_ptr(), b_in.data_ptr(), None, h.data_ptr(), M, mlp, d, 1, 1, 18, ws.data_ptr(), ws.numel(), s()) == 0
   assert lib.spa3d_op_linear(h.data_ptr(), w_out.data_ptr(), b_out.data_ptr(), a.data_ptr(), y.data_ptr(), M, d, mlp, 0, 1, 2, ws.data_ptr(), ws.numel(), s()) == 0
 
 
