@@ -70,7 +70,8 @@ struct MlpFusedArgs {
 };
 // diagnostic builds only (tools/ablate_mlp_fused.py compiles a SEPARATE library per mask, never the product): compile-time mask,
 // 1 h / hpre stores wrapped into a 1-MiB window (no HBM write stream), 2 no gelu arithmetic, 4 no LDS-DMA, 8 no MFMAs, 16 no y stores,
-// 32 s_memtime stamps at the phase seams (per-wave sums to MlpFusedArgs::dbg; shares, not run time)
+// 32 s_memtime stamps at the phase seams (per-wave sums to MlpFusedArgs::dbg; shares, not run time), 64 plain instead of non-temporal stores,
+// 128 no counted wait at the phase ends (WRONG results: timing only), 256 no phase barriers (WRONG results: timing only)
 #ifndef SPA3D_MF_ABLATE
 #define SPA3D_MF_ABLATE 0
 #endif
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_fwd_kernel(MlpFusedArgs g) {
       constexpr int KIND = decltype(kind_)::v, GQ0 = decltype(gq0_)::v, ST = decltype(st_)::v;
       unsigned long long t0 = 0, t1 = 0;
       if constexpr (MF_ABL & 32) t0 = mf_stamp();
-      MF_BAR();  // segment `seg` is visible to every wave; every wave has left the slot this phase refills
+      if constexpr (!(MF_ABL & 256)) MF_BAR();  // segment `seg` is visible to every wave; every wave has left the slot this phase refills
       if constexpr (MF_ABL & 32) { t1 = mf_stamp(); tsum[0] += t1 - t0; }
       const unsigned ln = lane_now(); const int hh = ln >> 5;
       const unsigned l16 = ln * 16u;
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_fwd_kernel(MlpFusedArgs g) {
       constexpr int NW = decltype(nw_)::v;
       unsigned long long t0 = 0;
       if constexpr (MF_ABL & 32) t0 = mf_stamp();
-      if (edge) MF_WAIT_VM(12); else MF_WAIT_VM(NW);
+      if constexpr (!(MF_ABL & 128)) { if (edge) MF_WAIT_VM(12); else MF_WAIT_VM(NW); }
       if constexpr (MF_ABL & 32) tsum[3] += mf_stamp() - t0;
       seg = seg + 1 == MF_NSEG ? 0 : seg + 1; slot = slot == 2 ? 0 : slot + 1;
     };
@@ -411,6 +412,7 @@ bool mlp_fused_fwd(spa3d_ctx* c, const bf16_t* na, const bf16_t* a, bf16_t* y, b
   g.dbg = nullptr;
   if (MF_ABL & 32) { const char* e = getenv("SPA3D_MF_DBG"); if (e) g.dbg = (unsigned long long*)strtoull(e, nullptr, 0); }
   g.nt_store = (c->nt_stream && (double)M * MF_H * 2.0 >= 512.0 * 1024 * 1024) ? 1 : 0;
+  if (MF_ABL & 64) g.nt_store = 0;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)mlp_fused_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS); attr = true; }
   ProfScope ps(c, PROF_GEMM_NT, 2.0 * 2.0 * (double)M * MF_D * MF_H, ((double)M * (3.0 * MF_D + 2.0 * MF_H) + 2.0 * MF_D * MF_H) * 2.0);

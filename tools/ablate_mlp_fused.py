@@ -43,7 +43,7 @@ torch.cuda.synchronize()
 res = {m: [] for m in masks}
 for rnd in range(5):
   for m in masks: res[m].append(timeit(lambda: run(m)))
-names = {32: 'stamps', 1: 'h/hpre stores to a 1-MiB window', 2: 'no gelu math', 4: 'no LDS-DMA', 8: 'no MFMA', 16: 'no y stores'}
+names = {256: 'no phase barriers (wrong results)', 128: 'no counted waits (wrong results)', 64: 'plain (not nt) stores', 32: 'stamps', 1: 'h/hpre stores to a 1-MiB window', 2: 'no gelu math', 4: 'no LDS-DMA', 8: 'no MFMA', 16: 'no y stores'}
 for m in masks:
   v = sorted(res[m]); lab = ' + '.join(names[k] for k in names if m & k) or 'full kernel'
   print(f'mask {m:2d} {lab:60s} median {v[len(v)//2]:7.3f} ms  min {v[0]:7.3f} ms   ({2*2*M*d*mlp/v[len(v)//2]/1e9:7.1f} TF/s-equivalent)', flush=True)
