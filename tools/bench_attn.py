@@ -2,6 +2,7 @@
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, spa3d
+if os.environ.get('SPA3D_TOOL_LIB'): spa3d._lib.LIB_PATH = os.environ['SPA3D_TOOL_LIB']  # tools/variants_attn.py: a diagnostic build
 lib = spa3d._lib.load()
 s = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 nseq, S, H, Dh = int(os.environ.get('NSEQ', 16384)), int(os.environ.get('S', 151)), 8, 96
