@@ -178,18 +178,6 @@ __device__ __forceinline__ void tile_flush(const char* wt, bf16_t* g0, int64_t l
   asm volatile("" ::: "memory");
 }
 
-#ifndef SPA3D_FWD_ROT
-#define SPA3D_FWD_ROT 1
-#endif
-constexpr int FWD_ROT = SPA3D_FWD_ROT;  // 0 none, 1 shipped; 2-4: alternatives timed by tools/variants_attn.py
-__device__ __forceinline__ int fwd_rot(unsigned b, int nw) {
-  if (FWD_ROT == 1) return (int)((b >> 8) & 1) * (nw / 2);
-  if (FWD_ROT == 2) return (int)(b >> 8);
-  if (FWD_ROT == 3) return (int)((b * 0x9E3779B1u) >> 29);
-  if (FWD_ROT == 4) return (int)(b >> 3);
-  return 0;
-}
-
 template <int KT, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs g) {
   constexpr int S_pad = KT * 16;
@@ -202,15 +190,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs g) {
   const int64_t row0 = g.seq_off ? (int64_t)g.seq_off[seq] : seq * g.S;       // first row of the sequence
   const int S = g.seq_off ? g.seq_off[seq + 1] - (int)row0 : g.S, E = g.H * DH;  // its length (wave-uniform)
   const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
-  // Tile -> wave map, rotated per workgroup.  The query tiles are dealt round-robin, so with QT % NW != 0 (S = 129: 9 tiles, S = 151: 10) the first
-  // QT % NW waves carry one tile more; wave i of every workgroup sits on SIMD i, so un-rotated the SAME SIMDs carry the extra tile of both
-  // workgroups of a CU (6 tile times against 4.5-5 on the others).  Workgroups b and b + 256 start on the same CU (8 XCDs x 32 CUs, one
-  // workgroup per CU and pass): they get rotations 0 and NW/2.  Placement changes speed only.
-  const int w = FWD_ROT == 0 ? (tid >> 6) : ((tid >> 6) + fwd_rot(blockIdx.x, NW)) & (NW - 1);
+  const int w = tid >> 6;
   const int QT = (S + 15) / 16;
 
   constexpr int RPP = NW * 16, NP = (S_pad + RPP - 1) / RPP, NT = (KT + NW - 1) / NW;
-  static_assert((NW & (NW - 1)) == 0, "rotation assumes a power-of-two wave count");
   // every global load of the problem is in flight before the first use: K rows, V rows, this wave's Q fragments
   RawRows<NP> rk, rv;
   rows_load<NP, RPP>(rk, g.k + row0 * g.ldk + h * DH, g.ldk, S);
