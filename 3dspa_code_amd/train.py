@@ -270,6 +270,17 @@ class TrainState:
     return {'train/loss': l3[0], 'train/position_loss': l3[1], 'train/visible_loss': l3[2], 'train/learning_rate': lr,
             'train/grad_norm': self.scratch[0], 'train/skipped': self.scratch[2], 'train/loss_scale_mult': self.scratch[4]}
 
+  def skipped_steps(self) -> int:
+    """Updates skipped so far because the gradient norm was not finite (device counter scratch[3]; reading it synchronises)."""
+    return int(self.scratch[3].item())
+
+  def check_finite(self):
+    """For a training loop's logging interval (one device read): in fp16 a skipped step is the loss-scale mechanism at work; in bf16 / fp32 there is
+    no scale to lower, so a skipped LAST step means the gradients themselves are NaN / inf and every later step will be skipped too -- where the
+    reference's optax update would have propagated the NaN into the parameters.  Raises FloatingPointError in that case instead of training on silently."""
+    if float(self.scratch[2].item()) != 0.0 and getattr(self.model, 'precision', 'fp16') != 'fp16':
+      raise FloatingPointError(f'non-finite gradient norm at step {self.step - 1} ({self.skipped_steps()} skipped updates so far)')
+
   def eval_step(self, batch, discretize: bool = True, noise=None):
     """train.py:189-213: forward pass + compute_loss on the current parameters, no update.  Returns (metrics, predictions) with the
     reference's metric keys 'eval/loss', 'eval/position_loss', 'eval/visible_loss' (device scalars).  Under data parallelism the two

@@ -109,6 +109,33 @@ def test_fp16_overflow_skips_the_update_and_halves_the_scale():
 
 
 @pytest.mark.gpu
+def test_bf16_nan_gradients_skip_the_update_and_check_finite_raises():
+  """outside fp16 a skipped update is not a loss-scale event -- the gradients themselves are NaN.  The update is still skipped
+  (parameters and moments untouched, where optax would have written NaN into them), and TrainState.check_finite() turns it into an error."""
+  import spa3d
+  cfg, batch, noise = _small_full_model_case()
+  gb = batch_to(batch, 'cuda')
+  for k in ('dino_features', 'depth_features'):
+    gb[k] = gb[k].bfloat16()
+  model = product_model(spa3d, cfg, 'bf16')
+  st = spa3d.TrainState(model, model.init(0, gb)['params'], learning_rate=1e-3, warmup_steps=0, total_steps=100)
+  st.train_step(gb, noise=noise.cuda())
+  st.check_finite()
+  assert st.skipped_steps() == 0
+  bad = dict(gb); bad['support_tracks'] = gb['support_tracks'].clone(); bad['support_tracks'][0, 0, 0, 0] = float('nan')
+  before = (st.flat.clone(), st.m.clone(), st.v.clone())
+  m1 = st.train_step(bad, noise=noise.cuda())
+  torch.cuda.synchronize()
+  assert float(m1['train/skipped']) == 1.0 and st.skipped_steps() == 1
+  assert torch.equal(st.flat, before[0]) and torch.equal(st.m, before[1]) and torch.equal(st.v, before[2])
+  with pytest.raises(FloatingPointError):
+    st.check_finite()
+  m2 = st.train_step(gb, noise=noise.cuda())  # a clean batch trains on
+  assert float(m2['train/skipped']) == 0.0
+  st.check_finite()
+
+
+@pytest.mark.gpu
 def test_fp16_shared_rows_every_query_on_one_frame_q512():
   """All 512 queries of every sample share ONE frame: one slot per sample, each pre-summed dqkv row is a sum over 512 members at loss-scale
   magnitude (kept in fp32 until the single 16-bit rounding)."""
