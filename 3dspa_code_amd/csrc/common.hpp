@@ -163,6 +163,7 @@ struct spa3d_ctx {
   int nt_stream = 1;      // non-temporal stores for 16-bit outputs >= 512 MB
   int embed_fused = 1;    // input embedding as ONE GEMM over the concatenated K written once, in compact row order (model.hip encode_chunk); gemm_impl 6 = the multi-pass path
   int mlp_fused = 1;      // track-encoder MLP forward as ONE sequence-resident kernel (mlp_fused.hip); gemm_impl 6 = the two tiled GEMMs
+  int rs_gemm = 1;        // K = 384 projections on the row-stationary kernel (gemm_rs.hip); gemm_impl 6 = the tiled kernels; 7 (ops) = required
   int poison = 0;         // spa3d_set_option "poison": NaN-fill the workspace before every chunk and every op output before its launch (tests)
   bool tn_colsum_fused = false;  // set by gemm_tn_bf16: the last call also produced GemmDesc::colsum_out
   Prof prof;
@@ -170,14 +171,15 @@ struct spa3d_ctx {
 
 // gemm_impl: 0 product dispatch | 1 generic kernels only | 2 tiled kernels, product tile choice (ops: error when unusable) -- and test hooks that put
 // SMALL problems on the big kernels: 3 every eligible GEMM on the 8-phase kernels (persistent forms included), 4 the same with the non-persistent
-// 128x384 kernel, 5 tiled without the single-buffer short-K kernel, 6 tiled GEMMs without the fused kernels (MLP forward as two GEMMs, multi-pass input embedding)
+// 128x384 kernel, 5 tiled without the single-buffer short-K kernel, 6 tiled GEMMs without the round-4 kernels (MLP forward as two GEMMs, multi-pass input embedding, no row-stationary
+// K = 384 kernel), 7 (ops only) the row-stationary kernel or an error
 inline void apply_gemm_impl(spa3d_ctx* c, int v) {
   c->gemm_impl = v == 1 ? 1 : (v >= 2 ? 2 : 0);
-  c->nt_8p = 1; c->nt_8pp = 5; c->tn_8p = 1; c->nt_occ = 1; c->mlp_fused = 1; c->embed_fused = 1;
+  c->nt_8p = 1; c->nt_8pp = 5; c->tn_8p = 1; c->nt_occ = 1; c->mlp_fused = 1; c->embed_fused = 1; c->rs_gemm = 1;
   if (v == 3 || v == 4) { c->nt_8p = 2; c->tn_8p = 2; }
   if (v == 4) c->nt_8pp = 1;
   if (v == 5) c->nt_occ = 0;
-  if (v == 6) { c->mlp_fused = 0; c->embed_fused = 0; }
+  if (v == 6) { c->mlp_fused = 0; c->embed_fused = 0; c->rs_gemm = 0; }
 }
 // attn_impl: 0 product dispatch | 1 generic composition (GEMMs + softmax kernels) | 2 fused kernels (ops: error when unusable) | 3 / 4 fused with the
 // split-pass backward on 4 / 8 waves also where the four-image kernel would run (S <= 160; tests)
@@ -249,6 +251,11 @@ template <typename T> void gemm_generic(spa3d_ctx* c, const GemmDesc& d);
 // tiled bf16 kernels (gemm_fast.hip).  Return false if the shape/layout is not supported.
 bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d);
 bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d);
+// row-stationary K = 384 GEMM (gemm_rs.hip): C[M,N] = A[M,384] . W (+ bias) with W pre-packed into the kernel's fragment stream (element (k, n) of W at w[k*sk + n*sn])
+bool gemm_rs_ok(int K, int N);
+int64_t gemm_rs_pack_elems(int N);
+template <typename S> void gemm_rs_pack(spa3d_ctx* c, const S* w, int64_t sk, int64_t sn, int N, bf16_t* wpk);
+bool gemm_rs(spa3d_ctx* c, const bf16_t* A, int64_t lda, const bf16_t* wpk, const float* bias, bf16_t* C, int64_t ldc, int64_t M, int N);
 // sequence-resident MLP forward for d = 384, mlp = 1536 (mlp_fused.hip): y = a + MLP(na), h / hpre kept; false = shape not covered
 template <typename S> void mlp_fused_pack(spa3d_ctx* c, const S* w_in /*[384][1536]*/, const S* w_out /*[1536][384]*/, bf16_t* wpk);
 int64_t mlp_fused_pack_elems();

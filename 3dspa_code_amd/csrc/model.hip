@@ -39,6 +39,7 @@ static const float L1_WEIGHT = 5000.0f, BCE_WEIGHT = 1e-8f;  // train.py:96
 template <typename T> struct Lin {
   T* wn = nullptr;            // [K][N]  (dX = dY . wn^T reads it K'-contiguous)
   T* wt = nullptr;            // [N][K]  (Y = X . W with K contiguous)
+  T* wpk = nullptr;           // K = 384: W as the row-stationary kernel's fragment stream (gemm_rs.hip); null = not built
   const float* bias = nullptr;
   int K = 0, N = 0, nseg = 1, segw = 0;
   int64_t ldn = 0;            // row stride of wn (== N except for column sub-views of a fused matrix)
@@ -104,11 +105,18 @@ template <typename T> struct Net {
     l.wn = alloc<T>((int64_t)K * l.N); l.wt = alloc<T>((int64_t)K * l.N);
     for (int s = 0; s < l.nseg; ++s)
       k_pack<T>(c, l.src[s], segw, K, segw, l.wn + (int64_t)s * segw, l.N, l.wt + (int64_t)s * segw * K, K);
+    if constexpr (sizeof(T) == 2) {
+      if (c->rs_gemm && c->gemm_impl != 1 && gemm_rs_ok(K, l.N) && segw % 64 == 0) {
+        l.wpk = alloc<T>(gemm_rs_pack_elems(l.N));
+        for (int s = 0; s < l.nseg; ++s) gemm_rs_pack<float>(c, l.src[s], segw, 1, segw, l.wpk + gemm_rs_pack_elems(segw) * s);
+      }
+    }
     return l;
   }
   // columns [seg0*segw, (seg0+nseg)*segw) of a fused matrix as a Lin of its own (no bias)
   static Lin<T> sub_lin(const Lin<T>& l, int seg0, int nseg) {
     Lin<T> r = l; r.nseg = nseg; r.N = nseg * l.segw; r.bias = nullptr; r.gb = nullptr;
+    r.wpk = l.wpk && gemm_rs_ok(l.K, r.N) ? l.wpk + gemm_rs_pack_elems(l.segw) * seg0 : nullptr;  // the stream is column-segment-major
     r.wn = l.wn + (int64_t)seg0 * l.segw; r.wt = l.wt + (int64_t)seg0 * l.segw * l.K;
     for (int i = 0; i < 3; ++i) { r.src[i] = i < nseg ? l.src[seg0 + i] : nullptr; r.gw[i] = i < nseg ? l.gw[seg0 + i] : nullptr; }
     return r;
@@ -188,6 +196,10 @@ template <typename T> struct Net {
   // Y[M,N] = epi(X[M,K] W + b) (+ residual)
   void lin_fwd(const Lin<T>& l, const T* X, void* Y, int64_t M, int epi = EPI_NONE, const T* residual = nullptr, int out_f32 = 0,
                int accumulate = 0, int64_t ldx = 0, int64_t ldy = 0, int crow_group = 0, int crow_skip = 0, T* pre_out = nullptr) {
+    if constexpr (sizeof(T) == 2) {
+      if (l.wpk && epi == EPI_NONE && !residual && !out_f32 && !accumulate && !crow_group && !pre_out && M >= 4096 &&
+          gemm_rs(c, X, ldx ? ldx : l.K, l.wpk, l.bias, (T*)Y, ldy ? ldy : l.N, M, l.N)) return;
+    }
     GemmDesc d{};
     d.A = X; d.B = l.wn; d.C = Y; d.M = M; d.N = l.N; d.K = l.K;
     d.sAm = ldx ? ldx : l.K; d.sAk = 1; d.sBk = l.ldn; d.sBn = 1; d.sCm = ldy ? ldy : l.N;

@@ -22,6 +22,13 @@ int op_linear(OpCtx& c, const T* A, const T* B, const float* bias, const T* res,
   d.bias = bias; d.epi = act ? EPI_GELU : EPI_NONE; d.aux = res;
   apply_gemm_impl(&c, impl & 15);
   if constexpr (sizeof(T) == 2) {
+    if ((impl & 15) == 7) {  // the row-stationary K = 384 kernel (gemm_rs.hip) or an error
+      if (act || res || !gemm_rs_ok(K, N)) return SPA3D_ERR_ARG;
+      T* pk = c.alloc<T>(gemm_rs_pack_elems(N));
+      if (c.ar.overflow) return SPA3D_ERR_WORKSPACE;
+      gemm_rs_pack<T>(&c, B, N, 1, N, pk);
+      return gemm_rs(&c, A, K, pk, bias, C, N, M, N) ? c.status() : SPA3D_ERR_ARG;
+    }
     if (impl != 1) {
       // impl | 16 (benchmarks): the MLP-in form of the step -- a second output stream (the pre-activation) from the same epilogue
       if (impl & 16) { d.pre_out = c.alloc<T>(M * N); if (c.ar.overflow) return SPA3D_ERR_WORKSPACE; }
