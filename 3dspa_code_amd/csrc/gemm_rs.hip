@@ -119,15 +119,16 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
   f32x16 S[2][2][2];  // [ping-pong][row block][32-column half]: register 4q+e = column 8q + 4hh + e of the half, of the lane's row
   int64_t st_row0 = 0; int st_col = 0; bool st_on = false, st_edge = false;  // the chunk waiting in the other accumulator set: its rows, columns, and whether stores are masked
 
-  auto load_a = [&](int tile) {
+  auto load_a = [&](int tile) {  // k-step-major: the first phase's MFMA group i needs fragments 2i, 2i+1 of both row blocks -- they arrive in that order
     const unsigned ln = rs_lane(); const int r = ln & 31, hh = ln >> 5;
+    const bf16_t* ap[2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
       int64_t row = (int64_t)tile * 256 + w * 64 + rb * 32 + r; if (row > g.M - 1) row = g.M - 1;
-      const bf16_t* ap = g.A + row * g.lda + hh * 8;
-#pragma unroll
-      for (int s = 0; s < 24; ++s) nb[rb][s] = *(const bf16x8*)(ap + 16 * s);
+      ap[rb] = g.A + row * g.lda + hh * 8;
     }
+#pragma unroll
+    for (int s = 0; s < 24; ++s) { nb[0][s] = *(const bf16x8*)(ap[0] + 16 * s); nb[1][s] = *(const bf16x8*)(ap[1] + 16 * s); }
   };
 
   // One phase on ring slot `slot`.  MF: the 96 MFMAs of output columns [64 cc, 64 cc + 64) into S[BUF] (bias-initialised).  The chunk in S[BUF ^ 1] (if st_on) leaves
@@ -158,23 +159,26 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
       for (int q = 0; q < 4; ++q) *(u32x2*)(wp + 16 * q) = u32x2{rs_pack2(X[4 * q], X[4 * q + 1]), rs_pack2(X[4 * q + 2], X[4 * q + 3])};
     };
     auto stage_rd = [&](int k) { sv = *(const u32x4*)(stg + (8 * k + (ln >> 3)) * 144 + (ln & 7) * 16); };
+    // this lane's store address of row group 0 (row st_row0 + (ln >> 3), 16-byte piece ln & 7 of the chunk's 128 B); row group k is 8 rows further
+    char* cp0 = (char*)(g.C + (st_row0 + (ln >> 3)) * g.ldc + st_col + (ln & 7) * 8);
+    const int64_t cstep = g.ldc * 16;  // bytes per 8 rows
     auto stage_st = [&](int k) {
-      const int64_t rw = st_row0 + 8 * k + (ln >> 3);
-      if (rw < g.M) {
-        const int64_t e2 = rw * g.ldc + st_col + (ln & 7) * 8;
-        u32x4* dp = (u32x4*)(g.C + ((RS_ABL & 1) ? (e2 & 0x7fff8) : e2));
-        if (g.nt_store) __builtin_nontemporal_store(sv, dp); else *dp = sv;
-      }
+      u32x4* dp = (u32x4*)(cp0 + k * cstep);
+      if constexpr (RS_ABL & 1) dp = (u32x4*)((char*)g.C + ((uintptr_t)((char*)dp - (char*)g.C) & 0xffff0));
+      if (st_edge) {  // uniform: only a tile that runs past M masks its stores
+        if (st_row0 + 8 * k + (int64_t)(ln >> 3) < g.M) { if (g.nt_store) __builtin_nontemporal_store(sv, dp); else *dp = sv; }
+      } else { if (g.nt_store) __builtin_nontemporal_store(sv, dp); else *dp = sv; }
     };
-    auto init_t = [&](int t) {
+    // the chunk's bias in the accumulator layout (register 4q+e = column 8q + 4hh + e of half t): it enters as the C operand of each chain's first MFMA
+    f32x16 bz[2];
+    auto load_bias = [&](int t) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 b = *(const f32x4*)(sbias + 64 * cc + 32 * t + 8 * q + 4 * hh);
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) { S[BUF][rb][t][4 * q] = b[0]; S[BUF][rb][t][4 * q + 1] = b[1]; S[BUF][rb][t][4 * q + 2] = b[2]; S[BUF][rb][t][4 * q + 3] = b[3]; }
+        bz[t][4 * q] = b[0]; bz[t][4 * q + 1] = b[1]; bz[t][4 * q + 2] = b[2]; bz[t][4 * q + 3] = b[3];
       }
     };
-    if constexpr (MF) init_t(0);
+    if constexpr (MF) load_bias(0);
 #pragma unroll
     for (int gq = 0; gq < 24; ++gq) {
       if constexpr (MF) {
@@ -182,24 +186,27 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
 #pragma unroll
           for (int i = 0; i < 2; ++i) fa[(gq + 2) % 3][i] = *(const bf16x8*)(sb + ((gq + 2) * 2 + i) * 1024);
         }
-        if (gq == 8) init_t(1);
+        if (gq == 8) load_bias(1);
       }
-      if (st_on && !(RS_ABL & 16)) {  // uniform
-        if (gq == 1) stage_wr(0, 0);
-        if (gq == 2) stage_wr(0, 1);
-        if (gq == 3) stage_wr(1, 0);
-        if (gq == 4) stage_wr(1, 1);
-        if (gq == 5) stage_rd(0);
-        if (gq >= 6 && gq <= 12) { stage_st(gq - 6); stage_rd(gq - 5); }
-        if (gq == 13) stage_st(7);
-      }
-      if constexpr (MF) {  // the drain pass issues no LDS-DMA
-        if (gq == 1) dma1(sg2, sl2, RsIC<9>(), l16);
-        if (gq == 2) dma1(sg2, sl2, RsIC<10>(), l16);
-        if (gq == 3) dma1(sg2, sl2, RsIC<11>(), l16);
-        if (gq == 14) dma1(sg2, sl2, RsIC<0>(), l16); if (gq == 15) dma1(sg2, sl2, RsIC<1>(), l16); if (gq == 16) dma1(sg2, sl2, RsIC<2>(), l16);
-        if (gq == 17) dma1(sg2, sl2, RsIC<3>(), l16); if (gq == 18) dma1(sg2, sl2, RsIC<4>(), l16); if (gq == 19) dma1(sg2, sl2, RsIC<5>(), l16);
-        if (gq == 20) dma1(sg2, sl2, RsIC<6>(), l16); if (gq == 21) dma1(sg2, sl2, RsIC<7>(), l16); if (gq == 22) dma1(sg2, sl2, RsIC<8>(), l16);
+      {  // one vector-memory instruction per group, stores and LDS-DMA alternating (8 + 12 in 24 groups; as two blocks -- stores in groups 6-13, LDS-DMA in 14-22 -- the
+         // kernel measured 6.20 ms against 5.75 at N = 2304; staggering the four waves behind the barrier with s_sleep: slower).  Row group k is read at group 4 + 2k and
+         // stored at 6 + 2k; piece j of the image's 9 KiB is free once row groups <= j have been read (rows 8k .. 8k+7 end at byte 1152 (k+1))
+        if (st_on && !(RS_ABL & 16)) {
+          if (gq == 0) stage_wr(0, 0);
+          if (gq == 1) stage_wr(0, 1);
+          if (gq == 2) stage_wr(1, 0);
+          if (gq == 3) stage_wr(1, 1);
+          if (gq >= 6 && gq <= 20 && !(gq & 1)) stage_st((gq - 6) >> 1);   // (the store first: it reads the register the next row group is read into)
+          if (gq >= 4 && gq <= 18 && !(gq & 1)) stage_rd((gq - 4) >> 1);
+        }
+        if constexpr (MF) {
+          if (gq == 1) dma1(sg2, sl2, RsIC<9>(), l16);
+          if (gq == 3) dma1(sg2, sl2, RsIC<10>(), l16);
+          if (gq == 5) dma1(sg2, sl2, RsIC<11>(), l16);
+          if (gq == 7) dma1(sg2, sl2, RsIC<0>(), l16); if (gq == 9) dma1(sg2, sl2, RsIC<1>(), l16); if (gq == 11) dma1(sg2, sl2, RsIC<2>(), l16);
+          if (gq == 13) dma1(sg2, sl2, RsIC<3>(), l16); if (gq == 15) dma1(sg2, sl2, RsIC<4>(), l16); if (gq == 17) dma1(sg2, sl2, RsIC<5>(), l16);
+          if (gq == 19) dma1(sg2, sl2, RsIC<6>(), l16); if (gq == 21) dma1(sg2, sl2, RsIC<7>(), l16); if (gq == 23) dma1(sg2, sl2, RsIC<8>(), l16);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (MF) {
@@ -207,8 +214,8 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
         const int t = gq / 12, s0 = 2 * (gq % 12);
         if constexpr (RS_ABL & 8) { asm volatile("" ::"v"(fa[gq % 3][0]), "v"(fa[gq % 3][1])); }
         else {
-          S[BUF][0][t] = MFMA32(fa[gq % 3][0], nb[0][s0], S[BUF][0][t]);
-          S[BUF][1][t] = MFMA32(fa[gq % 3][0], nb[1][s0], S[BUF][1][t]);
+          S[BUF][0][t] = MFMA32(fa[gq % 3][0], nb[0][s0], s0 == 0 ? bz[t] : S[BUF][0][t]);
+          S[BUF][1][t] = MFMA32(fa[gq % 3][0], nb[1][s0], s0 == 0 ? bz[t] : S[BUF][1][t]);
           S[BUF][0][t] = MFMA32(fa[gq % 3][1], nb[0][s0 + 1], S[BUF][0][t]);
           S[BUF][1][t] = MFMA32(fa[gq % 3][1], nb[1][s0 + 1], S[BUF][1][t]);
         }
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
     const bool edge = (int64_t)tile * 256 + 256 > g.M;
     unsigned long long th = 0;
     if constexpr (RS_ABL & 32) th = rs_stamp();
-    load_a(tile);
+    load_a(tile);  // (prefetching the next tile's rows behind the last phase was measured: the 48 loads -- 32-byte pieces of 32 rows each -- cost that phase what they cost here)
     if constexpr (RS_ABL & 32) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tsum[3] += rs_stamp() - th; }
     for (int c = 0; c < g.nseg; c += 2) {
       phase(RsIC<0>(), RsIC<1>(), c);
@@ -270,6 +277,9 @@ bool gemm_rs(spa3d_ctx* c, const bf16_t* A, int64_t lda, const bf16_t* wpk, cons
   g.A = A; g.lda = lda; g.C = C; g.ldc = ldc; g.wpk = (const char*)wpk; g.bias = bias; g.M = M; g.N = N; g.nseg = N / 64;
   g.tiles = (int)((M + 255) / 256);
   g.nt_store = (c->nt_stream && (double)M * N * 2.0 >= 512.0 * 1024 * 1024) ? 1 : 0;
+#ifdef SPA3D_RS_PLAIN_ST
+  g.nt_store = 0;
+#endif
   g.dbg = nullptr;
   if (RS_ABL & 32) { const char* e = getenv("SPA3D_RS_DBG"); if (e) g.dbg = (unsigned long long*)strtoull(e, nullptr, 0); }
   static bool attr = false;

@@ -40,6 +40,7 @@ template <typename T> struct Lin {
   T* wn = nullptr;            // [K][N]  (dX = dY . wn^T reads it K'-contiguous)
   T* wt = nullptr;            // [N][K]  (Y = X . W with K contiguous)
   T* wpk = nullptr;           // K = 384: W as the row-stationary kernel's fragment stream (gemm_rs.hip); null = not built
+  T* wpk_t = nullptr;         // N = 384 (one segment): W^T as that stream, for dX = dY . W^T
   const float* bias = nullptr;
   int K = 0, N = 0, nseg = 1, segw = 0;
   int64_t ldn = 0;            // row stride of wn (== N except for column sub-views of a fused matrix)
@@ -109,6 +110,10 @@ template <typename T> struct Net {
       if (c->rs_gemm && c->gemm_impl != 1 && gemm_rs_ok(K, l.N) && segw % 64 == 0) {
         l.wpk = alloc<T>(gemm_rs_pack_elems(l.N));
         for (int s = 0; s < l.nseg; ++s) gemm_rs_pack<float>(c, l.src[s], segw, 1, segw, l.wpk + gemm_rs_pack_elems(segw) * s);
+      }
+      if (c->rs_gemm && c->gemm_impl != 1 && G && l.nseg == 1 && gemm_rs_ok(l.N, K)) {  // training only: element (k' = n, n' = k) of W^T is src[k * N + n]
+        l.wpk_t = alloc<T>(gemm_rs_pack_elems(K));
+        gemm_rs_pack<float>(c, l.src[0], 1, l.N, K, l.wpk_t);
       }
     }
     return l;
@@ -210,6 +215,9 @@ template <typename T> struct Net {
   }
   // dX[M,K] (op)= dY[M,N] W^T, optionally * gelu'(pre)
   void lin_bwd_x(const Lin<T>& l, const T* dY, T* dX, int64_t M, const T* gelu_pre = nullptr, int accumulate = 0, int64_t lddx = 0) {
+    if constexpr (sizeof(T) == 2) {
+      if (l.wpk_t && !gelu_pre && !accumulate && M >= 4096 && gemm_rs(c, dY, l.N, l.wpk_t, nullptr, dX, lddx ? lddx : l.K, M, l.K)) return;
+    }
     GemmDesc d{};
     d.A = dY; d.B = l.wn; d.C = dX; d.M = M; d.N = l.K; d.K = l.N;
     d.sAm = l.N; d.sAk = 1; d.sBk = 1; d.sBn = l.ldn; d.sCm = lddx ? lddx : l.K;
