@@ -255,7 +255,9 @@ bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d);
 bool gemm_rs_ok(int K, int N);
 int64_t gemm_rs_pack_elems(int N);
 template <typename S> void gemm_rs_pack(spa3d_ctx* c, const S* w, int64_t sk, int64_t sn, int N, bf16_t* wpk);
-bool gemm_rs(spa3d_ctx* c, const bf16_t* A, int64_t lda, const bf16_t* wpk, const float* bias, bf16_t* C, int64_t ldc, int64_t M, int N);
+// gelu_pre != null: C = (A . W + bias) o gelu'(gelu_pre) (gelu_pre in C's layout, row stride ldpre): the MLP backward's dh
+bool gemm_rs(spa3d_ctx* c, const bf16_t* A, int64_t lda, const bf16_t* wpk, const float* bias, bf16_t* C, int64_t ldc, int64_t M, int N,
+             const bf16_t* gelu_pre = nullptr, int64_t ldpre = 0);
 // sequence-resident MLP forward for d = 384, mlp = 1536 (mlp_fused.hip): y = a + MLP(na), h / hpre kept; false = shape not covered
 template <typename S> void mlp_fused_pack(spa3d_ctx* c, const S* w_in /*[384][1536]*/, const S* w_out /*[1536][384]*/, bf16_t* wpk);
 int64_t mlp_fused_pack_elems();

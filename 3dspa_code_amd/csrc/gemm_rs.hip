@@ -56,11 +56,12 @@ __global__ void rs_pack_kernel(const S* __restrict__ w, int64_t sk, int64_t sn, 
 
 struct RsArgs {
   const bf16_t* A; int64_t lda; bf16_t* C; int64_t ldc; const char* wpk; const float* bias;
+  const bf16_t* aux; int64_t ldaux;  // AUX kernels: C = (A . W + bias) o gelu'(aux), aux in C's layout (the MLP backward's dh = (dy . W_out^T) o gelu'(hpre))
   int64_t M; int N, nseg, tiles, nt_store;
   unsigned long long* dbg;  // diagnostic builds with mask 32 only: per-wave cycle sums (s_memtime), else unused
 };
 // diagnostic builds only (tools/ablate_gemm_rs.py compiles a SEPARATE library per mask, never the product): compile-time mask, 1 stores wrapped into a 1-MiB window,
-// 4 no LDS-DMA, 8 no MFMAs, 16 no stores and no staging, 32 s_memtime stamps (per-wave sums to RsArgs::dbg), 128 no counted waits / 256 no barriers (WRONG results: timing only)
+// 2 (AUX) no gelu' arithmetic, 64 (AUX) no aux loads, 4 no LDS-DMA, 8 no MFMAs, 16 no stores and no staging, 32 s_memtime stamps (per-wave sums to RsArgs::dbg), 128 no counted waits / 256 no barriers (WRONG results: timing only)
 #ifndef SPA3D_RS_ABLATE
 #define SPA3D_RS_ABLATE 0
 #endif
@@ -85,7 +86,10 @@ template <int OFF> __device__ __forceinline__ void rs_glds(const void* base_unif
 #define RS_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define RS_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 template <int N_> struct RsIC { static constexpr int v = N_; };
+// compile-time loop (a `#pragma unroll` loop this large falls under LLVM's pragma-unroll size threshold, stays a loop, and the accumulator arrays go to scratch)
+template <int I, int N, typename F> __device__ __forceinline__ void rs_for(F&& f) { if constexpr (I < N) { f(RsIC<I>{}); rs_for<I + 1, N>(f); } }
 
+template <bool AUX>
 __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [3][48 KiB] ring | bias f32[N]
   const int tid = threadIdx.x;
@@ -118,6 +122,11 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
   bf16x8 nb[2][24];   // this wave's 64 A rows: row block rb, k-step s: lane (r, hh) holds A[row 32 rb + r][16 s + 8 hh .. + 7]
   f32x16 S[2][2][2];  // [ping-pong][row block][32-column half]: register 4q+e = column 8q + 4hh + e of the half, of the lane's row
   int64_t st_row0 = 0; int st_col = 0; bool st_on = false, st_edge = false;  // the chunk waiting in the other accumulator set: its rows, columns, and whether stores are masked
+  // AUX: aux values as the read-back steps want them (step j = rows 16 (j & 3) + (ln >> 2), columns 32 (j >> 2) + 8 (ln & 3) .. + 7), two chunks in flight: the phase that
+  // computes chunk c stores chunk c-1 with ax[(c-1) & 1] and reloads that set for chunk c+1.  The TWO-phase lead is for the compiler's waits: it counts the aux loads but
+  // cannot see the LDS-DMA instructions between them, so its s_waitcnt vmcnt(<= 7) ahead of a use also retires every LDS-DMA issued since -- with a one-phase lead that
+  // was everything issued ~6 MFMA groups earlier (6.4 ms at N = 1536, 4.3 ms with the loads removed); now its window is half a phase older.
+  u32x4 ax[2][8];
 
   auto load_a = [&](int tile) {  // k-step-major: the first phase's MFMA group i needs fragments 2i, 2i+1 of both row blocks -- they arrive in that order
     const unsigned ln = rs_lane(); const int r = ln & 31, hh = ln >> 5;
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
   // meanwhile: packed to 16 bit and written to the wave's own 12 KiB of the slot this phase refills in groups 1-4 (image [64 rows][128 B + 16]), read back as
   // whole 128-byte row pieces and stored, 8 rows per instruction, in groups 5-13; the LDS-DMA of segment seg + 2 follows into the image's 9 KiB in groups 14-22
   // (pieces 9-11, behind the image, go in groups 1-3).
-  auto phase = [&](auto buf_, auto mf_, int cc) {
+  auto phase = [&](auto buf_, auto mf_, int cc, int64_t nx_row0, int nx_col) {
     constexpr int BUF = decltype(buf_)::v; constexpr bool MF = decltype(mf_)::v;
     unsigned long long t0 = 0, t1 = 0;
     if constexpr (RS_ABL & 32) t0 = rs_stamp();
@@ -169,6 +178,38 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
         if (st_row0 + 8 * k + (int64_t)(ln >> 3) < g.M) { if (g.nt_store) __builtin_nontemporal_store(sv, dp); else *dp = sv; }
       } else { if (g.nt_store) __builtin_nontemporal_store(sv, dp); else *dp = sv; }
     };
+    // AUX: the waiting chunk goes through the image as f32, one 32-column half at a time ([64 rows][32 x 4 B + 16]: the same 9 KiB), so that the product with
+    // gelu'(aux) is formed in f32 and rounded once, as the tiled kernel's epilogue does.  Read-back step j: rows 16 (j & 3) + (ln >> 2), 8 columns per lane:
+    // 16 rows x 64 B per store instruction; ax[j] is reloaded for the chunk being computed right behind its use.
+    f32x4 v0, v1;
+    auto stage_wr32 = [&](int rb, int t) {
+      char* wp = stg + (rb * 32 + (ln & 31)) * 144 + 16 * hh;
+      const f32x16& X = S[BUF ^ 1][rb][t];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *(f32x4*)(wp + 32 * q) = f32x4{X[4 * q], X[4 * q + 1], X[4 * q + 2], X[4 * q + 3]};
+    };
+    auto stage_rd32 = [&](int j) { const char* rp = stg + (16 * (j & 3) + (ln >> 2)) * 144 + (ln & 3) * 32; v0 = *(const f32x4*)rp; v1 = *(const f32x4*)(rp + 16); };
+    char* cpa = (char*)(g.C + (st_row0 + (ln >> 2)) * g.ldc + st_col + (ln & 3) * 8);
+    float eo[8];  // one step's eight products; the step is spread over three MFMA groups (3 + 3 + 2 values) so that its ~130 VALU instructions ride behind
+                  // twelve MFMAs instead of four -- as one block per group the kernel measured 6.4 ms (tiled: 6.7), the MFMA pipe idle behind the VALU issue
+    auto ep_val = [&](int j, int e) {
+      const unsigned aw = ax[BUF ^ 1][j][e >> 1];
+      const float x = (e & 1) ? unpack_hi(aw) : unpack_lo(aw);
+      eo[e] = (e < 4 ? v0[e & 3] : v1[e & 3]) * ((RS_ABL & 2) ? x : gelu_tanh_grad_fast_f(x));
+    };
+    auto ep_store = [&](int j) {
+      const u32x4 ov = u32x4{rs_pack2(eo[0], eo[1]), rs_pack2(eo[2], eo[3]), rs_pack2(eo[4], eo[5]), rs_pack2(eo[6], eo[7])};
+      u32x4* dp = (u32x4*)(cpa + (j & 3) * (2 * cstep) + (j >> 2) * 64);
+      if constexpr (RS_ABL & 1) dp = (u32x4*)((char*)g.C + ((uintptr_t)((char*)dp - (char*)g.C) & 0xffff0));
+      if (st_edge) {
+        if (st_row0 + 16 * (j & 3) + (int64_t)(ln >> 2) < g.M) { if (g.nt_store) __builtin_nontemporal_store(ov, dp); else *dp = ov; }
+      } else { if (g.nt_store) __builtin_nontemporal_store(ov, dp); else *dp = ov; }
+    };
+    auto aux_ld = [&](int j) {  // of the chunk computed in the NEXT phase (columns nx_col of the tile at nx_row0), into the set this phase has just consumed
+      if constexpr (RS_ABL & 64) return;
+      int64_t row = nx_row0 + 16 * (j & 3) + (ln >> 2); if (row > g.M - 1) row = g.M - 1;
+      ax[BUF ^ 1][j] = *(const u32x4*)(g.aux + row * g.ldaux + nx_col + 32 * (j >> 2) + 8 * (ln & 3));
+    };
     // the chunk's bias in the accumulator layout (register 4q+e = column 8q + 4hh + e of half t): it enters as the C operand of each chain's first MFMA
     f32x16 bz[2];
     auto load_bias = [&](int t) {
@@ -179,8 +220,9 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
       }
     };
     if constexpr (MF) load_bias(0);
-#pragma unroll
-    for (int gq = 0; gq < 24; ++gq) {
+    if constexpr (AUX) { if (st_on && !(RS_ABL & 16)) { stage_wr32(0, 0); stage_wr32(1, 0); } }
+    rs_for<0, 24>([&](auto gq_) {
+      constexpr int gq = decltype(gq_)::v;
       if constexpr (MF) {
         if (gq + 2 < 24) {
 #pragma unroll
@@ -188,7 +230,26 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
         }
         if (gq == 8) load_bias(1);
       }
-      {  // one vector-memory instruction per group, stores and LDS-DMA alternating (8 + 12 in 24 groups; as two blocks -- stores in groups 6-13, LDS-DMA in 14-22 -- the
+      if constexpr (AUX) {
+        // step j = groups 3j .. 3j+2: its 16 rows of the f32 image are read at 3j, its store and the reload of ax[j] (for the chunk being computed) follow at 3j+3.
+        // Half 0 of the image was written ahead of group 0, half 1 is written at groups 10 / 11 (behind step 3's read).  LDS-DMA: pieces 9-11 (behind the
+        // image) early; pieces 2m, 2m+1 of the image's 9 KiB are free once step 4+m has read its rows (2304 bytes per step).
+        if (st_on && !(RS_ABL & 16)) {
+          if (gq % 3 == 0 && gq > 0) ep_store(gq / 3 - 1);
+          if (gq == 10) stage_wr32(0, 1);
+          if (gq == 11) stage_wr32(1, 1);
+          if (gq % 3 == 0) stage_rd32(gq / 3);
+        }
+        if constexpr (MF) {
+          if (gq % 3 == 0 && gq > 0) aux_ld(gq / 3 - 1);
+          if (gq == 1) dma1(sg2, sl2, RsIC<9>(), l16);
+          if (gq == 2) dma1(sg2, sl2, RsIC<10>(), l16);
+          if (gq == 4) dma1(sg2, sl2, RsIC<11>(), l16);
+          if (gq == 13) dma1(sg2, sl2, RsIC<0>(), l16); if (gq == 14) dma1(sg2, sl2, RsIC<1>(), l16); if (gq == 16) dma1(sg2, sl2, RsIC<2>(), l16);
+          if (gq == 17) dma1(sg2, sl2, RsIC<3>(), l16); if (gq == 19) dma1(sg2, sl2, RsIC<4>(), l16); if (gq == 20) dma1(sg2, sl2, RsIC<5>(), l16);
+          if (gq == 22) dma1(sg2, sl2, RsIC<6>(), l16); if (gq == 23) { dma1(sg2, sl2, RsIC<7>(), l16); dma1(sg2, sl2, RsIC<8>(), l16); }
+        }
+      } else {  // one vector-memory instruction per group, stores and LDS-DMA alternating (8 + 12 in 24 groups; as two blocks -- stores in groups 6-13, LDS-DMA in 14-22 -- the
          // kernel measured 6.20 ms against 5.75 at N = 2304; staggering the four waves behind the barrier with s_sleep: slower).  Row group k is read at group 4 + 2k and
          // stored at 6 + 2k; piece j of the image's 9 KiB is free once row groups <= j have been read (rows 8k .. 8k+7 end at byte 1152 (k+1))
         if (st_on && !(RS_ABL & 16)) {
@@ -210,8 +271,7 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (MF) {
-        constexpr int dummy = 0; (void)dummy;
-        const int t = gq / 12, s0 = 2 * (gq % 12);
+        constexpr int t = gq / 12, s0 = 2 * (gq % 12);
         if constexpr (RS_ABL & 8) { asm volatile("" ::"v"(fa[gq % 3][0]), "v"(fa[gq % 3][1])); }
         else {
           S[BUF][0][t] = MFMA32(fa[gq % 3][0], nb[0][s0], s0 == 0 ? bz[t] : S[BUF][0][t]);
@@ -220,13 +280,28 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
           S[BUF][1][t] = MFMA32(fa[gq % 3][1], nb[1][s0 + 1], S[BUF][1][t]);
         }
       }
+      if constexpr (AUX) {
+        if (st_on && !(RS_ABL & 16)) {
+          constexpr int j = gq / 3, part = gq % 3;
+          if (part == 0) { ep_val(j, 0); ep_val(j, 1); ep_val(j, 2); }
+          if (part == 1) { ep_val(j, 3); ep_val(j, 4); ep_val(j, 5); }
+          if (part == 2) { ep_val(j, 6); ep_val(j, 7); }
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (AUX) {  // step 7's store and reload
+      if (st_on && !(RS_ABL & 16)) ep_store(7);
+      if constexpr (MF) aux_ld(7);
     }
     if constexpr (RS_ABL & 32) { t0 = rs_stamp(); tsum[1] += t0 - t1; }
     if constexpr (MF) {
       // counted wait: this wave's pieces of segment seg + 1 (issued one phase earlier) have landed; this phase's 12 LDS-DMA and the (up to) 8 stores issued
       // before the last 9 of them may stay in flight (vmcnt retires in order).  Masked or absent stores are not counted on.
-      if constexpr (!(RS_ABL & 128)) { if (st_on && !st_edge && !(RS_ABL & 16)) RS_WAIT_VM(20); else RS_WAIT_VM(12); }
+      if constexpr (!(RS_ABL & 128)) {
+        if constexpr (AUX) { if (st_on && !st_edge && !(RS_ABL & 16)) RS_WAIT_VM(28); else RS_WAIT_VM(20); }   // + this phase's 8 aux loads
+        else { if (st_on && !st_edge && !(RS_ABL & 16)) RS_WAIT_VM(20); else RS_WAIT_VM(12); }
+      }
       if constexpr (RS_ABL & 32) tsum[2] += rs_stamp() - t0;
       seg = seg + 1 == g.nseg ? 0 : seg + 1; slot = slot == 2 ? 0 : slot + 1;
     }
@@ -239,14 +314,34 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
     if constexpr (RS_ABL & 32) th = rs_stamp();
     load_a(tile);  // (prefetching the next tile's rows behind the last phase was measured: the 48 loads -- 32-byte pieces of 32 rows each -- cost that phase what they cost here)
     if constexpr (RS_ABL & 32) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tsum[3] += rs_stamp() - th; }
-    for (int c = 0; c < g.nseg; c += 2) {
-      phase(RsIC<0>(), RsIC<1>(), c);
-      st_row0 = row0; st_col = 64 * c; st_on = true; st_edge = edge;
-      phase(RsIC<1>(), RsIC<1>(), c + 1);
+    const int ntile = tile + (int)gridDim.x < g.tiles ? tile + (int)gridDim.x : tile;
+    const int64_t nrow0 = (int64_t)ntile * 256 + w * 64;
+    if constexpr (AUX) {
+      if (tile == (int)blockIdx.x) {  // chunk 0's aux values (set 0): every later set is loaded two phases ahead of its use
+        const unsigned ln = rs_lane();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          int64_t row = row0 + 16 * (j & 3) + (ln >> 2); if (row > g.M - 1) row = g.M - 1;
+          ax[0][j] = *(const u32x4*)(g.aux + row * g.ldaux + 32 * (j >> 2) + 8 * (ln & 3));
+        }
+      }
+    }
+    // The tile's first two phases are PEELED: the A rows were requested just above and arrive while phase 0 runs (the compiler's waits for them count down
+    // through its MFMA groups).  Inside one loop those waits are executed by every phase that shares the code -- s_waitcnt vmcnt(9) .. vmcnt(3) in the middle of
+    // every other phase, each retiring nearly every LDS-DMA and store in flight -- or are hoisted as one vmcnt(0) ahead of the loop, which exposes the whole load.
+    phase(RsIC<0>(), RsIC<1>(), 0, row0, 64);                                                // computes chunk 0, stores the previous tile's last chunk (set 1), reloads set 1 for chunk 1
+    st_row0 = row0; st_col = 0; st_on = true; st_edge = edge;
+    phase(RsIC<1>(), RsIC<1>(), 1, row0, 128);                                               // computes 1, stores 0 (set 0), reloads set 0 for chunk 2
+    st_col = 64;
+    for (int c = 2; c < g.nseg; c += 2) {
+      phase(RsIC<0>(), RsIC<1>(), c, row0, 64 * (c + 1));                                   // computes chunk c, stores chunk c-1 (set 1), reloads set 1 for chunk c+1
+      st_col = 64 * c;
+      const bool last = c + 2 >= g.nseg;
+      phase(RsIC<1>(), RsIC<1>(), c + 1, last ? nrow0 : row0, last ? 0 : 64 * (c + 2));     // computes c+1, stores c (set 0), reloads set 0 for chunk c+2 / the next tile's 0
       st_col = 64 * (c + 1);
     }
   }
-  if (st_on) phase(RsIC<0>(), RsIC<0>(), 0);  // drain: the last chunk (in S[1]) leaves; no MFMAs, no LDS-DMA
+  if (st_on) phase(RsIC<0>(), RsIC<0>(), 0, 0, 0);  // drain: the last chunk (in S[1]) leaves; no MFMAs, no LDS-DMA
   RS_WAIT_VM(0);
   if constexpr (RS_ABL & 32) {
     if (g.dbg && rs_lane() == 0) {
@@ -270,11 +365,14 @@ bool gemm_rs_ok(int K, int N) { return K == RS_K && N >= 256 && N <= RS_MAXN && 
 int64_t gemm_rs_pack_elems(int N) { return (int64_t)(N / 64) * 48 * 512; }
 
 // C[M, N] = A[M, 384] . W (+ bias) with W as the packed stream.  Returns false when the shape / layout is not this kernel's.
-bool gemm_rs(spa3d_ctx* c, const bf16_t* A, int64_t lda, const bf16_t* wpk, const float* bias, bf16_t* C, int64_t ldc, int64_t M, int N) {
+bool gemm_rs(spa3d_ctx* c, const bf16_t* A, int64_t lda, const bf16_t* wpk, const float* bias, bf16_t* C, int64_t ldc, int64_t M, int N, const bf16_t* gelu_pre,
+             int64_t ldpre) {
   if (!wpk || !gemm_rs_ok(RS_K, N) || M < 1 || lda % 8 || ldc % 8 || (((uintptr_t)A | (uintptr_t)C) & 15)) return false;
+  if (gelu_pre && (ldpre % 8 || ((uintptr_t)gelu_pre & 15))) return false;
   if (c->dry) return true;
   RsArgs g{};
   g.A = A; g.lda = lda; g.C = C; g.ldc = ldc; g.wpk = (const char*)wpk; g.bias = bias; g.M = M; g.N = N; g.nseg = N / 64;
+  g.aux = gelu_pre; g.ldaux = ldpre;
   g.tiles = (int)((M + 255) / 256);
   g.nt_store = (c->nt_stream && (double)M * N * 2.0 >= 512.0 * 1024 * 1024) ? 1 : 0;
 #ifdef SPA3D_RS_PLAIN_ST
@@ -283,11 +381,16 @@ bool gemm_rs(spa3d_ctx* c, const bf16_t* A, int64_t lda, const bf16_t* wpk, cons
   g.dbg = nullptr;
   if (RS_ABL & 32) { const char* e = getenv("SPA3D_RS_DBG"); if (e) g.dbg = (unsigned long long*)strtoull(e, nullptr, 0); }
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_rs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS); attr = true; }
-  ProfScope ps(c, PROF_GEMM_NT, 2.0 * (double)M * N * RS_K, ((double)M * (RS_K + N) + (double)RS_K * N) * 2.0);
-  ps.tag(M, N, RS_K, 512);
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_rs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_rs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
+    attr = true;
+  }
+  ProfScope ps(c, PROF_GEMM_NT, 2.0 * (double)M * N * RS_K, ((double)M * (RS_K + N * (gelu_pre ? 2.0 : 1.0)) + (double)RS_K * N) * 2.0);
+  ps.tag(M, N, RS_K, gelu_pre ? 512 + 6 : 512);
   const int grid = g.tiles < 256 ? g.tiles : 256;
-  gemm_rs_kernel<<<grid, 256, RS_LDS, c->stream>>>(g);
+  if (gelu_pre) gemm_rs_kernel<true><<<grid, 256, RS_LDS, c->stream>>>(g);
+  else gemm_rs_kernel<false><<<grid, 256, RS_LDS, c->stream>>>(g);
   SPA_LAUNCH_CHECK(c);
   return true;
 }

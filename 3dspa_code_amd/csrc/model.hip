@@ -216,7 +216,7 @@ template <typename T> struct Net {
   // dX[M,K] (op)= dY[M,N] W^T, optionally * gelu'(pre)
   void lin_bwd_x(const Lin<T>& l, const T* dY, T* dX, int64_t M, const T* gelu_pre = nullptr, int accumulate = 0, int64_t lddx = 0) {
     if constexpr (sizeof(T) == 2) {
-      if (l.wpk_t && !gelu_pre && !accumulate && M >= 4096 && gemm_rs(c, dY, l.N, l.wpk_t, nullptr, dX, lddx ? lddx : l.K, M, l.K)) return;
+      if (l.wpk_t && !accumulate && M >= 4096 && gemm_rs(c, dY, l.N, l.wpk_t, nullptr, dX, lddx ? lddx : l.K, M, l.K, gelu_pre, l.K)) return;
     }
     GemmDesc d{};
     d.A = dY; d.B = l.wn; d.C = dX; d.M = M; d.N = l.K; d.K = l.N;

@@ -19,15 +19,15 @@ template <typename T>
 int op_linear(OpCtx& c, const T* A, const T* B, const float* bias, const T* res, T* C, int64_t M, int N, int K, int act, int impl) {
   GemmDesc d{};
   d.A = A; d.B = B; d.C = C; d.M = M; d.N = N; d.K = K; d.sAm = K; d.sAk = 1; d.sBk = N; d.sBn = 1; d.sCm = N;
-  d.bias = bias; d.epi = act ? EPI_GELU : EPI_NONE; d.aux = res;
+  d.bias = bias; d.epi = act == 1 ? EPI_GELU : (act == 2 ? EPI_MUL_GELU_GRAD : EPI_NONE); d.aux = res;  // act 2: C = (A.B + bias) o gelu'(residual)
   apply_gemm_impl(&c, impl & 15);
   if constexpr (sizeof(T) == 2) {
     if ((impl & 15) == 7) {  // the row-stationary K = 384 kernel (gemm_rs.hip) or an error
-      if (act || res || !gemm_rs_ok(K, N)) return SPA3D_ERR_ARG;
+      if (act == 1 || (act == 0 && res) || (act == 2 && !res) || !gemm_rs_ok(K, N)) return SPA3D_ERR_ARG;
       T* pk = c.alloc<T>(gemm_rs_pack_elems(N));
       if (c.ar.overflow) return SPA3D_ERR_WORKSPACE;
       gemm_rs_pack<T>(&c, B, N, 1, N, pk);
-      return gemm_rs(&c, A, K, pk, bias, C, N, M, N) ? c.status() : SPA3D_ERR_ARG;
+      return gemm_rs(&c, A, K, pk, bias, C, N, M, N, act == 2 ? res : nullptr, N) ? c.status() : SPA3D_ERR_ARG;
     }
     if (impl != 1) {
       // impl | 16 (benchmarks): the MLP-in form of the step -- a second output stream (the pre-activation) from the same epilogue

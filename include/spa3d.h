@@ -157,7 +157,7 @@ int spa3d_adamw_step(float* params, const float* grads, float* m, float* v, int6
  *   "chunk"           samples processed at a time; 0 = as many as fit the workspace
  *   "gemm_impl"       0 product dispatch | 1 generic strided MFMA kernel only | 2 tiled kernels | diagnostics that put small problems on the big
  *                     kernels: 3 every eligible GEMM on the 8-phase kernels, 4 the same with the non-persistent 128x384 kernel, 5 without the
- *                     single-buffer short-K kernel, 6 tiled GEMMs without the fused kernels (MLP forward as two GEMMs, multi-pass input embedding).  (The `impl` argument of spa3d_op_linear* takes
+ *                     single-buffer short-K kernel, 6 tiled GEMMs without the round-4 kernels (MLP forward as two GEMMs, multi-pass input embedding, no row-stationary K = 384 kernel).  (The `impl` argument of spa3d_op_linear* takes
  *                     the same values; spa3d_op_linear: | 16 = also write the pre-activation, the MLP-in form of the step.)
  *   "attn_impl"       0 product dispatch | 1 generic composition | 2 fused kernels | 3, 4 fused with the split-pass backward on 4 / 8 waves (tests)
  * and one test mode: "poison" 0/1 -- the workspace is filled with 16-bit NaN patterns before every sample chunk, so a read of a row that this
@@ -217,7 +217,9 @@ int spa3d_uniform_noise(float* out, int64_t n, uint32_t key0, uint32_t key1, voi
 int spa3d_op_sin_embed(const float* x, int64_t rows, int32_t C, int32_t nf, void* out, int32_t dtype, void* stream);
 
 /* C[M,N] = act(A[M,K] @ B[K,N] + bias) (+ residual); A,B,C,residual dense row-major `dtype`;
- * act: 0 none, 1 tanh-gelu.  impl: 0 auto, 1 generic kernel, 2 tiled bf16 kernel (error if unusable). */
+ * act: 0 none, 1 tanh-gelu, 2 = no activation and `residual` is not added but holds a pre-activation: C = (A @ B + bias) o gelu'(residual), the MLP backward's
+ * dh = (dy . W_out^T) o gelu'(hpre).  impl: 0 auto, 1 generic kernel, 2 tiled bf16 kernel (error if unusable), ... as "gemm_impl" above; 7 = the row-stationary
+ * K = 384 kernel (csrc/gemm_rs.hip: 16-bit, 128 | N <= 2304, act 0 or 2) or an error. */
 int spa3d_op_linear(const void* A, const void* B, const float* bias, const void* residual, void* C,
                     int64_t M, int32_t N, int32_t K, int32_t act, int32_t dtype, int32_t impl,
                     void* ws, int64_t ws_bytes, void* stream);

@@ -26,8 +26,9 @@ ws = torch.empty(1 << 26, dtype=torch.uint8, device='cuda')
 M = int(os.environ.get('M', 3065160)); N = int(os.environ.get('N', 2304))
 A = torch.randn(M, 384, device='cuda').bfloat16(); B = (torch.randn(384, N, device='cuda') / 384 ** 0.5).bfloat16(); bias = torch.randn(N, device='cuda')
 out_t = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+AUX = int(os.environ.get('AUX', 0)); pre = torch.randn(M, N, device='cuda').bfloat16() if AUX else None
 def run(m):
-  assert libs[m].spa3d_op_linear(A.data_ptr(), B.data_ptr(), bias.data_ptr(), None, out_t.data_ptr(), M, N, 384, 0, 1, 7, ws.data_ptr(), ws.numel(), s()) == 0
+  assert libs[m].spa3d_op_linear(A.data_ptr(), B.data_ptr(), None if AUX else bias.data_ptr(), pre.data_ptr() if AUX else None, out_t.data_ptr(), M, N, 384, 2 if AUX else 0, 1, 7, ws.data_ptr(), ws.numel(), s()) == 0
 def timeit(fn, n=5):
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   e0.record()
@@ -41,7 +42,7 @@ torch.cuda.synchronize()
 res = {m: [] for m in masks}
 for rnd in range(5):
   for m in masks: res[m].append(timeit(lambda: run(m)))
-names = {256: 'no barriers (wrong)', 128: 'no counted waits (wrong)', 32: 'stamps', 1: 'stores to a 1-MiB window', 4: 'no LDS-DMA', 8: 'no MFMA', 16: 'no staging / stores'}
+names = {2: "no gelu' math", 64: 'no aux loads', 256: 'no barriers (wrong)', 128: 'no counted waits (wrong)', 32: 'stamps', 1: 'stores to a 1-MiB window', 4: 'no LDS-DMA', 8: 'no MFMA', 16: 'no staging / stores'}
 for m in masks:
   v = sorted(res[m]); lab = ' + '.join(names[k] for k in names if m & k) or 'full kernel'
   print(f'N={N} {" ".join(extra)} mask {m:3d} {lab:50s} median {v[len(v)//2]:7.3f} ms  min {v[0]:7.3f} ms   ({2*M*N*384/v[len(v)//2]/1e9:7.1f} TF/s)', flush=True)

@@ -24,3 +24,12 @@ for N in (2304, 1536, 768):
     med, mn = timeit(f)
     print(f'M={M} N={N:5d} K=384 {name} median {med:7.3f} ms  min {mn:7.3f} ms  {2.0 * M * N * 384 / med / 1e9:7.1f} TF/s  {(M * (384 + N) * 2.0) / med / 1e6:7.1f} GB/s', flush=True)
   del A, B, out
+
+# the MLP backward's dh = (dy . W_out^T) o gelu'(hpre): act 2
+N = 1536
+A = torch.randn(M, 384, device='cuda').bfloat16(); B = (torch.randn(384, N, device='cuda') / 384 ** 0.5).bfloat16()
+pre = torch.randn(M, N, device='cuda').bfloat16(); out = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+for impl, name in ((7, 'row-stationary'), (6, 'tiled 8-phase ')):
+  f = lambda: lib.spa3d_op_linear(A.data_ptr(), B.data_ptr(), None, pre.data_ptr(), out.data_ptr(), M, N, 384, 2, 1, impl, ws.data_ptr(), ws.numel(), s())
+  med, mn = timeit(f)
+  print(f"M={M} N={N:5d} K=384 gelu' epilogue {name} median {med:7.3f} ms  min {mn:7.3f} ms  {2.0 * M * N * 384 / med / 1e9:7.1f} TF/s", flush=True)
