@@ -39,6 +39,15 @@ dbg = torch.zeros(256 * 4 * 4, dtype=torch.int64, device='cuda')
 os.environ['SPA3D_RS_DBG'] = str(dbg.data_ptr())
 for m in masks: run(m)
 torch.cuda.synchronize()
+if 0 in masks:  # correctness of the (variant) build on a row sample
+  out_t.fill_(float('nan')); run(0); torch.cuda.synchronize()
+  idx = torch.cat([torch.arange(0, 700, device='cuda'), torch.randint(0, M, (3000,), device='cuda'), torch.arange(M - 700, M, device='cuda')])
+  ref = A[idx].float() @ B.float() + (0 if AUX else bias)
+  if AUX:
+    x = pre[idx].float(); c = 0.7978845608028654; u = c * (x + 0.044715 * x ** 3); t = torch.tanh(u)
+    ref = ref * (0.5 * (1 + t) + 0.5 * x * (1 - t * t) * c * (1 + 3 * 0.044715 * x * x))
+  err = (out_t[idx].float() - ref).abs().max().item(); nan = int(torch.isnan(out_t.float()).sum().item())
+  print(f'check: max abs err on {idx.numel()} rows {err:.4f} (bf16 rounding ~ {ref.abs().max().item() * 2 ** -8:.4f}), NaNs in the whole output {nan}', flush=True)
 res = {m: [] for m in masks}
 for rnd in range(5):
   for m in masks: res[m].append(timeit(lambda: run(m)))
