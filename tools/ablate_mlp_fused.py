@@ -11,11 +11,12 @@ out = os.path.join(ROOT, 'tools', '_ablate'); os.makedirs(out, exist_ok=True)
 b.build(verbose=False)
 objs = [os.path.join(b.HERE, 'build', o) for o in sorted(os.listdir(os.path.join(b.HERE, 'build'))) if o.endswith('.o') and o != 'mlp_fused.o']
 masks = [int(x) for x in (sys.argv[1].split(',') if len(sys.argv) > 1 else '0,1,17,2,3,19,4,8,12,31'.split(','))]
+extra = [x for x in os.environ.get('VARIANT', '').split(',') if x]  # structure variants: VARIANT=-DSPA3D_MF_YSCHED=1
 import torch
 libs = {}
 for m in masks:
   ao = os.path.join(out, f'mlp_fused_abl{m}.o')
-  subprocess.check_call([b._hipcc()] + b.FLAGS + [f'-DSPA3D_MF_ABLATE={m}', '-c', os.path.join(b.CSRC, 'mlp_fused.hip'), '-o', ao])
+  subprocess.check_call([b._hipcc()] + b.FLAGS + [f'-DSPA3D_MF_ABLATE={m}'] + extra + ['-c', os.path.join(b.CSRC, 'mlp_fused.hip'), '-o', ao])
   lp = os.path.join(out, f'libspa3d_mf_abl{m}.so')
   subprocess.check_call([b._hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lp] + objs + [ao])
   libs[m] = C.CDLL(lp)
@@ -46,7 +47,7 @@ for rnd in range(5):
 names = {256: 'no phase barriers (wrong results)', 128: 'no counted waits (wrong results)', 64: 'plain (not nt) stores', 32: 'stamps', 1: 'h/hpre stores to a 1-MiB window', 2: 'no gelu math', 4: 'no LDS-DMA', 8: 'no MFMA', 16: 'no y stores'}
 for m in masks:
   v = sorted(res[m]); lab = ' + '.join(names[k] for k in names if m & k) or 'full kernel'
-  print(f'mask {m:2d} {lab:60s} median {v[len(v)//2]:7.3f} ms  min {v[0]:7.3f} ms   ({2*2*M*d*mlp/v[len(v)//2]/1e9:7.1f} TF/s-equivalent)', flush=True)
+  print(f'{" ".join(extra)} mask {m:2d} {lab:60s} median {v[len(v)//2]:7.3f} ms  min {v[0]:7.3f} ms   ({2*2*M*d*mlp/v[len(v)//2]/1e9:7.1f} TF/s-equivalent)', flush=True)
 if any(m & 32 for m in masks):
   t = dbg.view(256, 4, 8).double().cpu()
   tot = t.sum(dim=(0, 1)); lab = ['barrier', 'X body', 'Y body', 'end wait (vmcnt)', 'tile head', 'exposed gelu', 'epilogue', 'h/hpre stores']
