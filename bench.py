@@ -49,7 +49,7 @@ CONFIGS = {
 
 # profile class -> (bound, kernel-name prefixes in the rocprofv3 summaries under profiles/)
 CLASS_INFO = {
-    'gemm_nt_bf16': ('mfma', ('gemm_nt', 'mlp_fused_fwd')), 'gemm_tn_bf16': ('mfma', ('gemm_tn',)), 'gemm_generic': ('mfma', ('gemm_generic',)),
+    'gemm_nt_bf16': ('mfma', ('gemm_nt', 'mlp_fused_fwd', 'gemm_rs')), 'gemm_tn_bf16': ('mfma', ('gemm_tn',)), 'gemm_generic': ('mfma', ('gemm_generic',)),
     'attention_fused_fwd': ('hbm', ('attn_fwd', 'xattn_fwd', 'xattn_combine')), 'attention_fused_bwd': ('hbm', ('attn_bwd', 'xattn_dq_finish')),
     'layernorm_fwd': ('hbm', ('ln_fwd',)), 'layernorm_bwd': ('hbm', ('ln_bwd',)), 'attention_single_query': ('hbm', ('attn_q1',)),
     'embed': ('hbm', ()),  # the input-streaming stage north_star wants at the HBM roofline: live timing only (its kernels are shared with other classes)
