@@ -349,6 +349,20 @@ def main():
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
   dt = float(tmax.item())
   loss = float(metrics['train/loss'])
+  # N > 1 only, OUTSIDE the timed region: the same step with the gradient all-reduce in stream order behind the backward instead of under its last
+  # chunk -- the A/B of the overlap ("record the A/B in the JSON when a node appears").  Two extra steps per rank.
+  overlap_ab = None
+  if world > 1 and state._overlap is not None:
+    ov, state._overlap = state._overlap, None
+    sync()
+    t1 = time.perf_counter()
+    for _ in range(2):
+      state.train_step(batch)
+    sync()
+    t_off = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+    dist.all_reduce(t_off, op=dist.ReduceOp.MAX)
+    state._overlap = ov
+    overlap_ab = {'overlapped_ms_per_step': dt / args.steps * 1e3, 'stream_ordered_ms_per_step': float(t_off.item()) / 2 * 1e3, 'stream_ordered_steps': 2}
 
   if rank == 0:
     tracks = world * B * (N + Q) * args.steps
@@ -366,6 +380,8 @@ def main():
                                                                             else 'RCCL SUM after the backward'))},
         'roofline': roof,
     }
+    if overlap_ab:
+      out['config']['grad_allreduce_overlap_ab'] = overlap_ab
     if args.config in F_REF_FWD_PER_STEP_B64:
       scale = (B / 64.0) * (N / 2048.0) * (T / 150.0)  # F_ref scales ~linearly in B; other dims only for dev runs
       out['step_mfma_frac_F_ref'] = (3 * F_REF_FWD_PER_STEP_B64[args.config] * scale / (ms / 1e3)) / peak  # reference graph, nothing pruned
