@@ -202,7 +202,7 @@ template <typename T> struct Net {
   void lin_fwd(const Lin<T>& l, const T* X, void* Y, int64_t M, int epi = EPI_NONE, const T* residual = nullptr, int out_f32 = 0,
                int accumulate = 0, int64_t ldx = 0, int64_t ldy = 0, int crow_group = 0, int crow_skip = 0, T* pre_out = nullptr) {
     if constexpr (sizeof(T) == 2) {
-      if (l.wpk && epi == EPI_NONE && !residual && !out_f32 && !accumulate && !crow_group && !pre_out && M >= 4096 &&
+      if (l.wpk && epi == EPI_NONE && !residual && !out_f32 && !accumulate && !crow_group && !pre_out && M >= 512 &&
           gemm_rs(c, X, ldx ? ldx : l.K, l.wpk, l.bias, (T*)Y, ldy ? ldy : l.N, M, l.N)) return;
     }
     GemmDesc d{};
@@ -216,7 +216,7 @@ template <typename T> struct Net {
   // dX[M,K] (op)= dY[M,N] W^T, optionally * gelu'(pre)
   void lin_bwd_x(const Lin<T>& l, const T* dY, T* dX, int64_t M, const T* gelu_pre = nullptr, int accumulate = 0, int64_t lddx = 0) {
     if constexpr (sizeof(T) == 2) {
-      if (l.wpk_t && !accumulate && M >= 4096 && gemm_rs(c, dY, l.N, l.wpk_t, nullptr, dX, lddx ? lddx : l.K, M, l.K, gelu_pre, l.K)) return;
+      if (l.wpk_t && !accumulate && M >= 512 && gemm_rs(c, dY, l.N, l.wpk_t, nullptr, dX, lddx ? lddx : l.K, M, l.K, gelu_pre, l.K)) return;
     }
     GemmDesc d{};
     d.A = dY; d.B = l.wn; d.C = dX; d.M = M; d.N = l.K; d.K = l.N;
