@@ -140,10 +140,10 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
     for (int s = 0; s < 24; ++s) { nb[0][s] = *(const bf16x8*)(ap[0] + 16 * s); nb[1][s] = *(const bf16x8*)(ap[1] + 16 * s); }
   };
 
-  // One phase on ring slot `slot`.  MF: the 96 MFMAs of output columns [64 cc, 64 cc + 64) into S[BUF] (bias-initialised).  The chunk in S[BUF ^ 1] (if st_on) leaves
-  // meanwhile: packed to 16 bit and written to the wave's own 12 KiB of the slot this phase refills in groups 1-4 (image [64 rows][128 B + 16]), read back as
-  // whole 128-byte row pieces and stored, 8 rows per instruction, in groups 5-13; the LDS-DMA of segment seg + 2 follows into the image's 9 KiB in groups 14-22
-  // (pieces 9-11, behind the image, go in groups 1-3).
+  // One phase on ring slot `slot`.  MF: the 96 MFMAs of output columns [64 cc, 64 cc + 64) into S[BUF] (bias as the first MFMA's C operand).  The chunk in S[BUF ^ 1] (if
+  // st_on) leaves meanwhile through the wave's own 12 KiB of the slot this phase refills (image [64 rows][128 B + 16] = 9 KiB): packed to 16 bit and written in groups 0-3,
+  // read back as whole 128-byte row pieces and stored, 8 rows per instruction, interleaved with the LDS-DMA of segment seg + 2 (schedules below).  (nx_row0, nx_col): AUX only,
+  // the rows / first column of the chunk the NEXT phase computes (its aux values are requested two phases ahead of their use).
   auto phase = [&](auto buf_, auto mf_, int cc, int64_t nx_row0, int nx_col) {
     constexpr int BUF = decltype(buf_)::v; constexpr bool MF = decltype(mf_)::v;
     unsigned long long t0 = 0, t1 = 0;

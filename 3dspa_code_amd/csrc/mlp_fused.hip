@@ -10,11 +10,11 @@
 //   * S^T[hidden 64][rows 32] = W_in^T-chunk . na^T accumulates with the TOKEN ROW ON THE LANE, so gelu(S) packs straight into the B
 //     operand of the next product Y^T[out 384][rows 32] += W_out^T-chunk . P (k order permuted, cdna_hip_programming.md section 3
 //     "An accumulator tile as the next MFMA's operand": the packed W_out fragments carry the same permutation);
-//   * Y^T lives in 192 accumulator registers per lane for the whole tile, initialised with b_out + a (the residual);
-//   * h / hpre leave from registers as 16-byte pieces (v_permlane32_swap pairs the two lane halves), y through a wave-private LDS tile.
-// Phase = 48 MFMAs (32x32x16) on one 48-KiB ring slot: X_c = GEMM1 of hidden chunk c, Y_c = GEMM2 of chunk c-1; gelu(chunk c) is VALU
-// work spread over Y_c and X_{c+1}.  One barrier per phase; the LDS-DMA of segment p+2 is issued in phase p and waited for with a
-// COUNTED vmcnt at the end of phase p+1's predecessor (never 0 in the tile), so the h / hpre stores of a chunk have two phases to drain.
+//   * Y^T lives in 192 accumulator registers per lane for the whole tile (zero-initialised; b_out and the residual a are added in the epilogue);
+//   * h / hpre leave during the GEMM2 phases through the wave's own 12 KiB of the ring slot that phase refills, as whole 128-byte row pieces; y through the same scratch.
+// Phase = 48 MFMAs (32x32x16) on one 48-KiB ring slot: X_c = GEMM1 of hidden chunk c (ping-pong accumulators) with all eight gelu quads of chunk c-1 riding along,
+// Y_c = GEMM2 of chunk c-1 with that chunk's stores.  One barrier per phase; the LDS-DMA of segment p+2 is issued in phase p and waited for with a COUNTED vmcnt at the end
+// of phase p+1 (never 0 in the tile), so the h / hpre stores of a chunk have two phases to drain.  Measurements, ablations and what bounds it: DESIGN.md, "Round 4".
 #include <cstdlib>
 
 #include "common.hpp"
