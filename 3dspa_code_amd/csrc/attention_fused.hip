@@ -263,6 +263,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs g) {
         for (int j = 0; j < 8; ++j) t[j] = f2bf(acc[2 * s2 + (j >> 2)][j & 3] * inv);
         pb[s2] = __builtin_bit_cast(mfma16x8, t);
       }
+      // odd KT (S = 129: nine key tiles, not ten): the last key tile enters as a half-filled k = 32 product (elements 4-7 of both operands zero)
+      mfma16x8 ph;
+      if constexpr (KT & 1) {
+        u16x8 t8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { t8[j] = f2bf(acc[KT - 1][j] * inv); t8[4 + j] = 0; }
+        ph = __builtin_bit_cast(mfma16x8, t8);
+      }
       // ---- O^T[d][q] = sum_keys V^T[d][key] P^T[key][q]
       const int tq = fr >> 2, tp = fr & 3;  // this lane's slot in its 16-lane transposed-read group
       const char* vbase = Vs + tp * 8 + row_off(4 * fq + tq);
@@ -274,6 +282,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs g) {
           constexpr int s2 = decltype(sc_)::value;
           lo[s2] = lds_tr16_b64_o<dt * 32 + 2 * s2 * ROW16>(vbase); hi[s2] = lds_tr16_b64_o<dt * 32 + (2 * s2 + 1) * ROW16>(vbase);
         });
+        uint2 lo_last = make_uint2(0, 0);
+        if constexpr (KT & 1) lo_last = lds_tr16_b64_o<dt * 32 + (KT - 1) * ROW16>(vbase);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);  // MFMAs must stay below the wait (cdna_hip_programming.md rule 18)
 #pragma unroll
@@ -281,6 +291,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs g) {
           const uint4 vu = make_uint4(lo[s2].x, lo[s2].y, hi[s2].x, hi[s2].y);
           oacc = MFMA16(__builtin_bit_cast(mfma16x8, vu), pb[s2], oacc);
         }
+        if constexpr (KT & 1) oacc = MFMA16(__builtin_bit_cast(mfma16x8, make_uint4(lo_last.x, lo_last.y, 0u, 0u)), ph, oacc);  // upper half of k: zeros on both sides
         u16x4 o4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o4[r] = f2bf(oacc[r]);
@@ -514,7 +525,8 @@ bool attn_fused_fwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const b
   AttnArgs a; a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.sq = sq; a.sk = sk; a.km = km;
   a.S = Sk; a.H = H; a.nprob = nseq * H; a.o = o; a.lse = lse; a.seq_off = seq_off;
   const double rows = total_rows > 0 ? (double)total_rows : (double)nseq * Sk;  // ragged: rows actually present
-  const int KT = ((Sk + 31) / 32) * 2;
+  int KT = (Sk + 15) / 16;        // key / query tiles of 16; odd counts pair up (the last pair half empty) except nine (S = 129, the readout stack: its own instance)
+  if ((KT & 1) && KT != 9) KT += 1;
   ProfScope ps(c, PROF_ATTN_FWD, 4.0 * rows * H * (rows / nseq) * Dh, rows * H * Dh * 2.0 * 4.0);
   ps.tag(nseq, Sk, H, 0);
   switch (KT) {
@@ -522,6 +534,7 @@ bool attn_fused_fwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const b
     case 4: launch_fwd<4, 4>(c, a); break;
     case 6: launch_fwd<6, 4>(c, a); break;
     case 8: launch_fwd<8, 4>(c, a); break;
+    case 9: launch_fwd<9, 4>(c, a); break;
     case 10: launch_fwd<10, 4>(c, a); break;
     case 12: launch_fwd<12, 4>(c, a); break;
     case 14: launch_fwd<14, 8>(c, a); break;   // > 80 KiB of LDS: one workgroup per CU, so eight waves
@@ -587,9 +600,10 @@ __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, c
                                                ) {
   const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
   const float alpha = 0.10206207261596575f;  // 1/sqrt(96)
-  mfma16x8 dsb[KT / 2];
+  constexpr int NPAIR = (KT + 1) / 2;  // odd KT (nine tiles at S = 129): the last pair's second key tile does not exist -- zeros on both MFMA operands
+  mfma16x8 dsb[NPAIR];
 #pragma unroll
-  for (int s2 = 0; s2 < KT / 2; ++s2) {
+  for (int s2 = 0; s2 < NPAIR; ++s2) {
 #ifdef SPA3D_ABLATE
     if (ablate & 8) {  // what a dS tile handed over through LDS would cost this role: one 16-byte read per key-tile pair, no S / dP work
       dsb[s2] = *(const mfma16x8*)(Vs + 2 * s2 * ROW16 + row_off(fr) + fq * 16);
@@ -600,6 +614,11 @@ __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, c
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       const int kt = 2 * s2 + hf;
+      if (kt >= KT) {  // compile-time after unrolling
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[hf * 4 + r] = 0;
+        continue;
+      }
       f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
       if constexpr (FAST) { st = f32x4{mq, mq, mq, mq}; dpt = f32x4{dq_, dq_, dq_, dq_}; }
 #pragma unroll
@@ -631,15 +650,16 @@ __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, c
   static_for<0, 6>([&](auto dtc) {
     constexpr int dt = decltype(dtc)::value;
     dqa[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    uint2 lo[KT / 2], hi[KT / 2];
-    static_for<0, KT / 2>([&](auto sc_) {
+    uint2 lo[NPAIR], hi[NPAIR];
+    static_for<0, NPAIR>([&](auto sc_) {
       constexpr int s2 = decltype(sc_)::value;
-      lo[s2] = lds_tr16_b64_o<dt * 32 + 2 * s2 * ROW16>(kbase); hi[s2] = lds_tr16_b64_o<dt * 32 + (2 * s2 + 1) * ROW16>(kbase);
+      lo[s2] = lds_tr16_b64_o<dt * 32 + 2 * s2 * ROW16>(kbase);
+      if constexpr (2 * s2 + 1 < KT) hi[s2] = lds_tr16_b64_o<dt * 32 + (2 * s2 + 1) * ROW16>(kbase); else hi[s2] = make_uint2(0u, 0u);
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s2 = 0; s2 < KT / 2; ++s2) {
+    for (int s2 = 0; s2 < NPAIR; ++s2) {
       const uint4 u = make_uint4(lo[s2].x, lo[s2].y, hi[s2].x, hi[s2].y);
       dqa[dt] = MFMA16(__builtin_bit_cast(mfma16x8, u), dsb[s2], dqa[dt]);
     }
@@ -697,12 +717,18 @@ __device__ __forceinline__ void bwd_key_tile(const char* Qs, const char* dOs, co
   f32x4 dva[6], dka[6];
 #pragma unroll
   for (int dt = 0; dt < 6; ++dt) { dva[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dka[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll 1
-  for (int s2 = 0; s2 < KT / 2; ++s2) {
+  // one pair of query tiles (2 s2, 2 s2 + 1); SECOND = false: the last pair of an odd KT (nine tiles at S = 129) holds one tile -- zeros on both MFMA operands for the other
+  auto pair_step = [&](int s2, auto second_) {
+    constexpr bool SECOND = decltype(second_)::value;
     u16x8 tp_, tds;
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       const int qt = 2 * s2 + hf;
+      if (!SECOND && hf == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { tp_[4 + r] = 0; tds[4 + r] = 0; }
+        continue;
+      }
       f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dpt = f32x4{0.f, 0.f, 0.f, 0.f};
       if constexpr (FAST) { st = *(const f32x4*)(mrow + qt * 16 + fq * 4); dpt = *(const f32x4*)(drow + qt * 16 + fq * 4); }
 #pragma unroll
@@ -738,8 +764,9 @@ __device__ __forceinline__ void bwd_key_tile(const char* Qs, const char* dOs, co
     const char* ob = dOs + roff; const char* qb_ = Qs + roff;
     static_for<0, 6>([&](auto dtc) {
       constexpr int dt = decltype(dtc)::value;
-      olo[dt] = lds_tr16_b64_o<dt * 32>(ob); ohi[dt] = lds_tr16_b64_o<ROW16 + dt * 32>(ob);
-      qlo[dt] = lds_tr16_b64_o<dt * 32>(qb_); qhi[dt] = lds_tr16_b64_o<ROW16 + dt * 32>(qb_);
+      olo[dt] = lds_tr16_b64_o<dt * 32>(ob); qlo[dt] = lds_tr16_b64_o<dt * 32>(qb_);
+      if constexpr (SECOND) { ohi[dt] = lds_tr16_b64_o<ROW16 + dt * 32>(ob); qhi[dt] = lds_tr16_b64_o<ROW16 + dt * 32>(qb_); }
+      else { ohi[dt] = make_uint2(0u, 0u); qhi[dt] = make_uint2(0u, 0u); }
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -750,7 +777,10 @@ __device__ __forceinline__ void bwd_key_tile(const char* Qs, const char* dOs, co
       dva[dt] = MFMA16(__builtin_bit_cast(mfma16x8, uo), pb, dva[dt]);
       dka[dt] = MFMA16(__builtin_bit_cast(mfma16x8, uq), dsb, dka[dt]);
     }
-  }
+  };
+#pragma unroll 1
+  for (int s2 = 0; s2 < KT / 2; ++s2) pair_step(s2, std::true_type{});
+  if constexpr (KT & 1) pair_step(KT / 2, std::false_type{});
   // lane: key = k0 + fr, d = 16dt + 4fq + r
   float x[6][4]; float ss = 0.f;
 #pragma unroll
@@ -1183,6 +1213,8 @@ bool attn_fused_bwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const b
 #ifdef SPA3D_ABLATE
   { const char* e = getenv("SPA3D_ABLATE"); a.ablate = e ? atoi(e) : 0; }
 #endif
+  // even tile counts only: the tile routines take an odd KT (the last pair half empty, as in the forward's nine-tile instance), but at S = 129 the backward
+  // measured the same with nine tiles as with ten (3.43 vs 3.44-3.6 ms: its third ROUND of tiles, not the tenth key tile, is what S = 129 pays for there)
   const int KT = ((Sk + 31) / 32) * 2;
   ProfScope ps(c, PROF_ATTN_BWD, 14.0 * rows * H * (rows / nseq) * Dh, rows * H * Dh * 2.0 * 8.0);
   ps.tag(nseq, Sk, H, 0);
