@@ -211,12 +211,12 @@ def test_16bit_gradients_agree_with_fp32_along_the_fp32_trajectory(precision):
         f'worst significant leaf {worst}')
   gt = Gates(f'{precision} gradients vs fp32 gradients at 30 states of an fp32 training run (the states themselves move in the last bits run to run)')
   if precision == 'bf16':
-    gt.le('1 - cosine, worst of the first 10 states', 1.0 - min(cosines[:10]), 1.6e-3, '6.6e-4 ... 1.04e-3 (three runs)')
-    gt.le('1 - cosine, worst of all 30 states', 1.0 - min(cosines), 5e-3, '3.2e-3 ... 3.9e-3')
-    gt.le('worst leaf holding >= 1 % of the norm, relative', worst[0], 0.25, '0.19 ... 0.21')
+    gt.le('1 - cosine, worst of the first 10 states', 1.0 - min(cosines[:10]), 2.2e-3, '6.6e-4 ... 1.49e-3 (nine runs: the fp32 trajectory itself moves run to run)')
+    gt.le('1 - cosine, worst of all 30 states', 1.0 - min(cosines), 6.6e-3, '2.5e-3 ... 4.4e-3 (nine runs)')
+    gt.le('worst leaf holding >= 1 % of the norm, relative', worst[0], 0.31, '0.18 ... 0.21')
   else:
-    gt.le('1 - cosine, worst of all 30 states', 1.0 - min(cosines), 1e-3, '5.2e-4 ... 7.9e-4: (1 - cos) five times smaller than bf16')
-    gt.le('worst leaf holding >= 1 % of the norm, relative', worst[0], 0.125, '8.1e-2 ... 9.4e-2')
+    gt.le('1 - cosine, worst of all 30 states', 1.0 - min(cosines), 1.6e-3, '5.2e-4 ... 1.05e-3 (nine runs): (1 - cos) four to five times smaller than bf16')
+    gt.le('worst leaf holding >= 1 % of the norm, relative', worst[0], 0.147, '8.1e-2 ... 9.8e-2')
   gt.check()
 
 
