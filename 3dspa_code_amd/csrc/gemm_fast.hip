@@ -1326,9 +1326,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs g) {
 #pragma unroll
     for (int u = 0; u < QP; ++u) {
 #pragma unroll
+#if defined(SPA3D_TN_ABL) && (SPA3D_TN_ABL & 1)  // diagnostic build only (tools/ablate_gemm_tn.py): half of the transposed reads (WRONG results: timing only)
+      for (int j = 0; j < WNT; ++j) { fb[u][j][0] = ds_read_tr16_b64(sq + u * QB + offb[j][0]); fb[u][j][1] = fb[u][j][0]; }
+#pragma unroll
+      for (int i = 0; i < WIT; ++i) { fa[u][i][0] = ds_read_tr16_b64(sq + u * QB + offa[i][0]); fa[u][i][1] = fa[u][i][0]; }
+#else
       for (int j = 0; j < WNT; ++j) { fb[u][j][0] = ds_read_tr16_b64(sq + u * QB + offb[j][0]); fb[u][j][1] = ds_read_tr16_b64(sq + u * QB + offb[j][1]); }
 #pragma unroll
       for (int i = 0; i < WIT; ++i) { fa[u][i][0] = ds_read_tr16_b64(sq + u * QB + offa[i][0]); fa[u][i][1] = ds_read_tr16_b64(sq + u * QB + offa[i][1]); }
+#endif
     }
     if (q + D < nqp) {   // the next phase's quarters have landed (this wave's part); D - QP quarters stay in flight
 #pragma unroll
@@ -1345,7 +1351,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs g) {
         const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(fa[u][i][0].x, fa[u][i][0].y, fa[u][i][1].x, fa[u][i][1].y));
 #pragma unroll
         for (int j = 0; j < WNT; ++j)
+#if defined(SPA3D_TN_ABL) && (SPA3D_TN_ABL & 2)  // no MFMAs (timing only)
+          asm volatile("" ::"v"(af), "v"(fb[u][j][0]), "v"(fb[u][j][1]));
+#else
           acc[i][j] = MFMA32(af, __builtin_bit_cast(bf16x8, make_uint4(fb[u][j][0].x, fb[u][j][0].y, fb[u][j][1].x, fb[u][j][1].y)), acc[i][j]);
+#endif
       }
     if (do_cs) {
 #pragma unroll
