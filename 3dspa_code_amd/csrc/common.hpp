@@ -29,6 +29,7 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsi
 typedef __attribute__((ext_vector_type(8))) _Float16 mfma16x8;
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define MFMA32_ASM "v_mfma_f32_32x32x16_f16"
 #define DOT2C_F32_16 "v_dot2c_f32_f16"
 #define ONES2_16 0x3C003C00u  // (1.0, 1.0)
 #else
@@ -40,6 +41,7 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsi
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma16x8;
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA32_ASM "v_mfma_f32_32x32x16_bf16"
 #define DOT2C_F32_16 "v_dot2c_f32_bf16"
 #define ONES2_16 0x3F803F80u  // (1.0, 1.0)
 #endif
@@ -159,6 +161,7 @@ struct spa3d_ctx {
   int nt_8p = 1;          // 8-phase NT kernels (256x256 / 128x384): 1 for M >= 16 384, 2 for any M (tests), 0 off
   int nt_8pp = 5;         // their persistent forms: 5 both tiles (default), 1 the 256x256 one only (tests: the non-persistent 128x384 kernel), 0 off
   int tn_8p = 1;          // 8-phase TN (dW) kernels: 1 by size, 2 forced (tests), 0 off
+  int tn_big = 1;         // large-register-tile TN (dW) kernel (gemm_tnb.hip): 1 by size, 2 forced (tests), 0 off (gemm_impl 6 / 8)
   int nt_occ = 1;         // single-buffer 4-workgroups/CU NT kernel for K <= 512; 0 (tests) = the double-buffered kernel
   int nt_stream = 1;      // non-temporal stores for 16-bit outputs >= 512 MB
   int embed_fused = 1;    // input embedding as ONE GEMM over the concatenated K written once, in compact row order (model.hip encode_chunk); gemm_impl 6 = the multi-pass path
@@ -170,16 +173,18 @@ struct spa3d_ctx {
 };
 
 // gemm_impl: 0 product dispatch | 1 generic kernels only | 2 tiled kernels, product tile choice (ops: error when unusable) -- and test hooks that put
-// SMALL problems on the big kernels: 3 every eligible GEMM on the 8-phase kernels (persistent forms included), 4 the same with the non-persistent
+// SMALL problems on the big kernels: 3 every eligible GEMM on the 8-phase kernels (persistent forms included; dW on the 8-wave kernels), 4 the same with the non-persistent
 // 128x384 kernel, 5 tiled without the single-buffer short-K kernel, 6 tiled GEMMs without the round-4 kernels (MLP forward as two GEMMs, multi-pass input embedding, no row-stationary
-// K = 384 kernel), 7 (ops only) the row-stationary kernel or an error
+// K = 384 kernel, no round-5 large-tile dW kernel), 7 (ops only) the row-stationary kernel or an error, 8 the product dispatch without the round-5 large-tile dW kernel, 9 = 3 with every divisible dW on the large-tile kernel
 inline void apply_gemm_impl(spa3d_ctx* c, int v) {
   c->gemm_impl = v == 1 ? 1 : (v >= 2 ? 2 : 0);
-  c->nt_8p = 1; c->nt_8pp = 5; c->tn_8p = 1; c->nt_occ = 1; c->mlp_fused = 1; c->embed_fused = 1; c->rs_gemm = 1;
-  if (v == 3 || v == 4) { c->nt_8p = 2; c->tn_8p = 2; }
+  c->nt_8p = 1; c->nt_8pp = 5; c->tn_8p = 1; c->tn_big = 1; c->nt_occ = 1; c->mlp_fused = 1; c->embed_fused = 1; c->rs_gemm = 1;
+  if (v == 3 || v == 4) { c->nt_8p = 2; c->tn_8p = 2; c->tn_big = 0; }
+  if (v == 9) { c->nt_8p = 2; c->tn_8p = 2; c->tn_big = 2; }
   if (v == 4) c->nt_8pp = 1;
   if (v == 5) c->nt_occ = 0;
-  if (v == 6) { c->mlp_fused = 0; c->embed_fused = 0; c->rs_gemm = 0; }
+  if (v == 6) { c->mlp_fused = 0; c->embed_fused = 0; c->rs_gemm = 0; c->tn_big = 0; }
+  if (v == 8) c->tn_big = 0;
 }
 // attn_impl: 0 product dispatch | 1 generic composition (GEMMs + softmax kernels) | 2 fused kernels (ops: error when unusable) | 3 / 4 fused with the
 // split-pass backward on 4 / 8 waves also where the four-image kernel would run (S <= 160; tests)

@@ -16,6 +16,7 @@
 //   global_atomic_add_f32 -- one accumulator register of a 32x32 tile is two 128-B row segments per
 //   wave-instruction, the full-rate atomic shape (MI355X_MICROARCH.md "Global float atomics").
 #include "common.hpp"
+#include "tn_args.hpp"
 
 namespace SPA_NS {
 
@@ -1058,16 +1059,6 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
 // =================================================================================================================
 // TN: C[Ki][N] += sum_m A[m][Ki] * B[m][N]
 // =================================================================================================================
-struct TnArgs {
-  const bf16_t* A; const bf16_t* B; float* C; const bf16_t* zero;
-  int64_t M; int Ki; int N; int64_t lda, ldb, ldc;
-  int tiles_i, tiles_n, splits; int64_t rows_per_split;
-  int brow_group, brow_skip;
-  float* colsum;  // 8-phase kernels only: colsum[n] += sum_m B[m][n] (the bias gradient), nullptr = off
-  // 8-phase kernels only: the N output columns are seg_n-wide segments that live in different buffers (the q / k / v kernels of a fused
-  // projection are separate leaves): columns [s seg_n, (s+1) seg_n) go to Cseg[s - 1] for s >= 1, row stride ldc in each.  0 = one buffer.
-  int seg_n; float* Cseg[2];
-};
 
 __device__ __forceinline__ uint2 ds_read_tr16_b64(const void* p) {
   uint2 v;
@@ -1449,6 +1440,13 @@ bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d) {
   g.seg_n = d.seg_n; g.Cseg[0] = (float*)d.C_seg[0]; g.Cseg[1] = (float*)d.C_seg[1];
   if (d.seg_n > 0 && (d.seg_n % 32 || N % d.seg_n || N / d.seg_n > 3 || d.colsum_out)) return false;
   c->tn_colsum_fused = false;
+  if (c->tn_big && (M >= 65536 || c->tn_big == 2) && ((Ki % 384 == 0 && N % 256 == 0) || (Ki % 256 == 0 && N % 384 == 0))) {  // large register tile (gemm_tnb.hip)
+    ProfScope ps(c, PROF_GEMM_TN, 2.0 * (double)M * Ki * N, ((double)M * Ki + (double)M * N) * 2.0);
+    ps.tag(M, N, Ki, 1 << 20);
+    g.colsum = d.colsum_out;
+    if (gemm_tnb(c, g)) { c->tn_colsum_fused = d.colsum_out != nullptr; SPA_LAUNCH_CHECK(c); return true; }
+    g.colsum = nullptr; ps.on = false;
+  }
   if (c->tn_8p && (M >= 65536 || c->tn_8p == 2) && (g.brow_group == 0 || g.brow_group >= 16)) {
     // tile shape with the least padding: 384 x 128 / 128 x 384 when one dimension is an odd multiple of 384, else 256 x 256
     auto waste = [&](int TI, int TNN) { return (double)((Ki + TI - 1) / TI * TI) * ((N + TNN - 1) / TNN * TNN) / ((double)Ki * N); };

@@ -298,6 +298,15 @@ def test_linear_bwd_tiled_8phase(lib, M, N, K):
   test_linear_bwd_tiled(lib, M, N, K, impl=3)
 
 
+@pytest.mark.parametrize('M,N,K', [(3333, 2304, 384), (9000, 768, 1280), (70001, 384, 768), (4097, 1536, 384), (640, 1280, 1536), (256, 768, 768),
+                                   (100000, 256, 384), (288, 384, 256), (12320, 1280, 2304), (544, 1536, 1280)])
+def test_linear_bwd_large_register_tile(lib, M, N, K):
+  """dB = A^T.dC on the round-5 large-register-tile TN kernel (csrc/gemm_tnb.hip: 384 x 256 / 256 x 384 workgroup tiles, 384 accumulators per wave, the M % 32
+  rows through the tail kernel), forced for any M (impl 9); both tile orientations, one and several tiles per dimension, M below one ring (6 quarters) and
+  M with and without a tail.  Backward of a Dense, /root/reference/attention.py:106-107,154-183."""
+  test_linear_bwd_tiled(lib, M, N, K, impl=9)
+
+
 @pytest.mark.parametrize('bwd_mode', ['1', '2', '3'])
 @pytest.mark.parametrize('nseq,S,H,masked', [(5, 25, 8, True), (3, 129, 8, False), (4, 151, 8, True), (2, 128, 8, False), (3, 40, 2, True),
                                              (17, 151, 8, True), (3, 301, 8, True), (2, 200, 8, False), (2, 320, 4, True), (9, 193, 2, True), (3, 176, 8, True), (2, 160, 4, False)])
