@@ -31,7 +31,7 @@ def _stale(out, deps):
 
 def build(force: bool = False, verbose: bool = True) -> str:
   hipcc = _hipcc()
-  hdrs = [os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'tn_args.hpp'), os.path.join(HERE, '..', 'include', 'spa3d.h')]
+  hdrs = [os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'tn_args.hpp'), os.path.join(CSRC, 'ablate.inc'), os.path.join(HERE, '..', 'include', 'spa3d.h')]
   objdir = os.path.join(HERE, 'build')
   os.makedirs(objdir, exist_ok=True)
   srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
@@ -46,7 +46,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
   def cc(job):
     src, obj, extra = job
-    cmd = [hipcc] + FLAGS + extra + ['-c', src, '-o', obj]
+    cmd = [hipcc] + FLAGS + extra + ['-USPA3D_ABLATION_BUILD', '-c', src, '-o', obj]
+    # the product library never carries a work-skipping diagnostic switch (csrc/ablate.inc)
+    assert not any('ABL' in f for f in FLAGS + extra), 'ablation flags are for tools/ablate_*.py only'
     if verbose:
       print(' '.join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../include/spa3d.h"
+#include "ablate.inc"  // every work-skipping diagnostic mask, all 0 in libspa3d_hip.so
 
 // One translation unit is compiled for exactly ONE 16-bit activation type: bf16 (default) or IEEE fp16 (-DSPA_F16=1, BASELINE
 // cfg#5).  The raw 16-bit storage type is `bf16_t` (unsigned short) in both builds; what differs -- the two conversions, the MFMA
@@ -329,14 +330,14 @@ template <typename T> void k_share_reduce(spa3d_ctx*, const T* src, const int32_
 template <typename T> void k_assemble_readout_bwd(spa3d_ctx*, const T* dseq, const int32_t* qframe, int64_t B, int Q, int L, int Cl, int D,
                                                   T* dqtok, float* dlat);
 void k_loss_fwd(spa3d_ctx*, const float* head, int64_t nq, int T_, const float* tgt, const float* tvis, float* tracks, float* vlog,
-                float* clog, float* sums, int NC = 3);
+                float* clog, float* sums, unsigned* poison, int NC = 3);
 void k_loss_from_preds(spa3d_ctx*, const float* tracks, const float* vlog, int64_t n, const float* tgt, const float* tvis, float* sums,
-                       int NC = 3);
+                       unsigned* poison, int NC = 3);
 template <typename T> void k_loss_bwd(spa3d_ctx*, const float* head, int64_t nq, int T_, const float* tgt, const float* tvis,
                                       const float* denom_dev, float l1w, float bcew, T* dhead, int NC = 3, const float* scale_dev = nullptr);
-void k_vis_count(spa3d_ctx*, const float* tvis, int64_t n, float* out);
-void k_set_denom(spa3d_ctx*, const float* sums, float denom_host, float* denom_dev);
-void k_loss_finalize(spa3d_ctx*, const float* sums, const float* denom_dev, float l1w, float bcew, float* loss3);
+void k_vis_count(spa3d_ctx*, const float* tvis, int64_t n, float* out, unsigned* poison);
+void k_set_denom(spa3d_ctx*, const float* sums, const unsigned* poison, float denom_host, float* denom_dev);
+void k_loss_finalize(spa3d_ctx*, const float* sums, const unsigned* poison, const float* denom_dev, float l1w, float bcew, float* loss3);
 void k_adamw(spa3d_ctx*, float* p, const float* g, float* m, float* v, int64_t n, float lr, int64_t step, float clip, float b1, float b2,
              float eps, float wd, float* scratch);
 void k_uniform_noise(spa3d_ctx*, float* out, int64_t n, uint32_t k0, uint32_t k1);

@@ -8,16 +8,24 @@
 // Registers.  384 accumulators do not fit one register file (256 VGPR + 256 AGPR per lane at one wave per SIMD) and hipcc picks ONE file for all MFMA
 // results of a kernel (AGPR at this occupancy): the round-4 version spilled 112-176 registers.  The MFMAs are therefore inline assembly with the
 // accumulator file chosen per tile: 16 tiles "+a" (256 AGPRs, all of them), 8 tiles "+v" (128 VGPRs), which leaves 128 VGPRs for the fragments
-// (3 x 4 x 2 sets + 8 x 4), 14 lane constants of the read addressing, the two staging offsets and temporaries.
+// (3 x 4 x 2 sets + 8 x 4), the read / staging addresses and temporaries.  0 spilled registers.
 //
-// Layout.  The reduction runs over "quarters" of 16 m-rows.  A quarter in LDS = five [16 rows][128 columns] sub-images in the transposed-read layout of
-// gemm_fast.hip (tr_off): A's 3 (2) then B's 2 (3) = 20 KiB, one LDS-DMA of 1 KiB per wave and sub-image (rows 4w .. 4w+3).  Ring of 8 quarters
-// = 160 KiB.  Phase = 2 quarters = 48 MFMAs per wave between two barriers; phase p issues the LDS-DMA of quarters 2p+6, 2p+7 into the slots of quarters
-// 2p-2, 2p-1 (last read in phase p-1) and ends with vmcnt(15) (this wave's pieces of quarters <= 2p+4 landed) + s_barrier.  There is no second wave
-// per SIMD to hide LDS latency behind, so the fragment reads are pipelined by hand: while the MFMAs of quarter q issue (wide tile j = 0..7, three
-// MFMAs each), the narrow operand's fragments of quarter q+1 go into a second register set and wide fragment j of quarter q+1 replaces fragment j
-// right behind its last MFMA.  Reads and LDS-DMA are untracked inline asm; every fragment has 20 younger LDS operations at its first use (LDS
-// operations return in order), so ONE s_waitcnt lgkmcnt(15) -- the counter's maximum -- ahead of each MFMA triple is exact enough.
+// Layout.  The reduction runs over "quarters" of 16 m-rows.  A quarter in LDS = five [16 rows][128 columns] sub-images (A's 3 (2), then B's 2 (3)) = 20 KiB.
+// A sub-image is four 1-KiB pieces (rows 4g .. 4g+3), one LDS-DMA instruction each (wave w stages piece w of every sub-image: 4 rows x 256 B of global
+// memory), and INSIDE a piece the order is [32-column tile t][row r][64 B]: the 4 rows x 64 B that one 32-lane half of ds_read_b64_tr_b16 takes are 256
+// contiguous bytes (conflict-free without a swizzle) and every tile / half / sub-image of a fragment read is an INSTRUCTION OFFSET from one lane address
+// (the first version used the XOR-swizzled 256-B rows of gemm_fast.hip: 14 lane constants and a v_add per read, and the kernel is issue-bound -- 22 adds
+// per quarter were 11 % of its time, tools/ablate_tnb.py mask 16).
+// Ring of 8 quarters = 160 KiB.  Phase = 2 quarters = 48 MFMAs per wave between two barriers; phase p issues the LDS-DMA of quarters 2p+6, 2p+7 into the slots
+// of quarters 2p-2, 2p-1 (last read in phase p-1) and ends with vmcnt(15) (this wave's pieces of quarters <= 2p+4 landed) + s_barrier.
+//
+// Schedule.  One wave per SIMD: nothing hides what the wave's own in-order stream does not, so every MFMA is followed by at most one or two other
+// instructions (an MFMA holds vector issue for 8 of its 32 cycles).  Quarter q, triple j = the three MFMAs of wide tile j:
+//     T0: the narrow operand's fragments of quarter q+1 (second register set), one tile behind each MFMA
+//     Tj (j = 1..7): wide fragment j-1 of quarter q+1 replaces fragment j-1 behind MFMAs 0 and 1 (its last use was triple j-1);
+//                    behind MFMA 2: one LDS-DMA piece (j = 1..5), the next quarter's read addresses (j = 6), wide fragment 7 (j = 7)
+// Reads and LDS-DMA are untracked inline asm; LDS operations return in order, so two counted waits per quarter are exact: lgkmcnt(8) ahead of T0 (all but
+// wide fragments 4..7 of the previous quarter's reads have returned) and lgkmcnt(12) ahead of T4 (this quarter has issued 12 reads by then).
 //
 // Rows.  The kernel takes whole phases only: M % 32 rows of the reduction go to a small scalar tail kernel, so no lane ever needs a bounds test or a
 // zero page and both operands are addressed as (wave-uniform 64-bit base in SGPRs) + (32-bit lane offset) + (instruction offset).
@@ -39,13 +47,12 @@ typedef mfma16x8 bf16x8;
 // subtracts it from the M0 value)
 #define TNB_GLDS(voff, sbase, m0v, IMM) \
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(sbase), "s"(m0v), "n"(IMM) : "memory", "m0")
-// transposed fragment read at (slot base in an SGPR) + (lane constant) + IMM
-#define TNB_DSRD(dst, sq, lc, IMM)                                                                                                          \
-  do {                                                                                                                                      \
-    unsigned t__;                                                                                                                           \
-    asm volatile("v_add_u32 %1, %2, %3\n\tds_read_b64_tr_b16 %0, %1 offset:%4" : "=v"(dst), "=&v"(t__) : "s"(sq), "v"(lc), "n"(IMM) : "memory"); \
-  } while (0)
+// transposed fragment read at (lane address) + IMM.  A function, not a macro: clang does not capture a name that a generic lambda uses only as an asm operand
+template <int IMM> __device__ __forceinline__ void tnb_rd(uint2& dst, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM) : "memory");
+}
 
+constexpr int TNB_ABL = SPA3D_ABL_TNB;  // csrc/ablate.inc: 0 in libspa3d_hip.so
 template <int N_> struct TnIC { static constexpr int v = N_; };
 // compile-time loop (a `#pragma unroll` loop this large falls under LLVM's pragma-unroll size threshold and stays a loop: accumulators in scratch)
 template <int I, int N, typename F> __device__ __forceinline__ void tn_for(F&& f) { if constexpr (I < N) { f(TnIC<I>{}); tn_for<I + 1, N>(f); } }
@@ -75,11 +82,11 @@ __global__ __launch_bounds__(256, 1) void gemm_tnb_kernel(TnArgs g) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
 
-  // ---- staging: piece s of a quarter = sub-image s, rows 4w .. 4w+3; lane -> (row sr, physical 16-B chunk scp)
-  const int sr = lane >> 4, scp = lane & 15, r16 = 4 * w + sr;
-  const int chs = scp ^ (((r16 & 3) << 2) | ((r16 >> 2) & 3));  // the source chunk that lands in physical chunk scp (the swizzle is applied on the source side)
-  unsigned voffA = (unsigned)(((int64_t)r16 * g.lda + i0 + chs * 8) * 2);
-  unsigned voffB = (unsigned)(((int64_t)r16 * g.ldb + n0 + chs * 8) * 2);
+  // ---- staging: piece (sub-image s, row group w); lane -> (tile st, row sr of the group, 16-B chunk sc of the tile's 64-B row): LDS-DMA writes lane-linear,
+  // so this IS the [tile][row][64 B] order inside the piece
+  const int st = lane >> 4, sr = (lane >> 2) & 3, sc = lane & 3, r16 = 4 * w + sr;
+  unsigned voffA = (unsigned)(((int64_t)r16 * g.lda + i0 + 32 * st + 8 * sc) * 2);
+  unsigned voffB = (unsigned)(((int64_t)r16 * g.ldb + n0 + 32 * st + 8 * sc) * 2);
   const char* sA = (const char*)(g.A + mbeg * g.lda);
   const char* sB;
   int boff = 0; unsigned skipB = 0; int G = 0;
@@ -95,12 +102,13 @@ __global__ __launch_bounds__(256, 1) void gemm_tnb_kernel(TnArgs g) {
   const unsigned stepA = (unsigned)(32 * g.lda), stepB = (unsigned)(32 * g.ldb);  // 16 rows in bytes
   int si = 0;                                  // ring slot the next staged quarter goes to
   unsigned m0s = lds0 + (unsigned)w * 1024u;   // its LDS address for this wave's row group
+  bool in_loop = false;                        // (diagnostic builds: the prologue always stages)
   auto stage_piece = [&](auto s_) {
     constexpr int s = decltype(s_)::v;
     constexpr int IMM = 256 * (s < NSA ? s : s - NSA);   // the sub-image's first column in bytes
     const unsigned m0v = m0s + (unsigned)(s * 4096 - IMM);
     const unsigned vo = s < NSA ? voffA : voffB; const char* sb = s < NSA ? sA : sB;  // locals: clang does not capture names used only as asm operands
-    TNB_GLDS(vo, sb, m0v, IMM);
+    if (!(TNB_ABL & 1) || !in_loop) TNB_GLDS(vo, sb, m0v, IMM);
   };
   auto stage_advance = [&]() {
     sA += stepA; sB += stepB;
@@ -108,22 +116,15 @@ __global__ __launch_bounds__(256, 1) void gemm_tnb_kernel(TnArgs g) {
     if constexpr (REMAP) { boff += 16; const bool wrap = boff >= G; boff = wrap ? boff - G : boff; voffB = wrap ? voffB + skipB : voffB; }
   };
 
-  // ---- transposed-read addressing (gemm_tn_kernel): 16-lane group gq covers operand index 16 (gq & 1) .. +15 and k = 8 (gq >> 1) .. +7.
-  // Byte offset of tile t's fragment inside its sub-image = tr_off(row, 4 t + cbase) = (256 row + 16 (cbase ^ swz(row)) + 8 (lp & 1)) ^ 64 t
+  // ---- transposed-read addressing: 16-lane group gq covers operand index 16 (gq & 1) .. +15 and k = 8 (gq >> 1) .. +7; lane 4 lq + lp of the group supplies row
+  // k0 + lq, chunk 2 (gq & 1) + (lp >> 1), + 8 (lp & 1) bytes.  Half h of a fragment = rows + 4 h = the next piece.  Byte offset inside a quarter of
+  // (sub-image s, tile t, half h) = 4096 s + 1024 (2 (gq >> 1) + h) + 256 t + 64 lq + 16 chunk + 8 (lp & 1): one lane constant + an instruction offset
   const int gq = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
-  const int kq = 8 * (gq >> 1) + lq;
-  const int cbase = 2 * (gq & 1) + (lp >> 1);
-  const int swz0 = ((kq & 3) << 2) | ((kq >> 2) & 3), swz1 = (((kq + 4) & 3) << 2) | (((kq + 4) >> 2) & 3);
-  const unsigned lb0 = (unsigned)(256 * kq + 16 * (cbase ^ swz0) + 8 * (lp & 1)), lb1 = (unsigned)(256 * (kq + 4) + 16 * (cbase ^ swz1) + 8 * (lp & 1));
-  unsigned wl[4][2], nl[3][2];  // lane constants: wide tile j uses wl[j & 3] (+ its sub-image as the instruction offset), narrow tile i uses nl[i]
+  const unsigned lc = (unsigned)(2048 * (gq >> 1) + 64 * lq + 16 * (2 * (gq & 1) + (lp >> 1)) + 8 * (lp & 1));
+  unsigned lcn[3];  // the wave's narrow tiles 3w .. 3w+2 straddle the sub-images: their sub-image / tile offsets ride in the lane constant
 #pragma unroll
-  for (int t = 0; t < 4; ++t) { wl[t][0] = lb0 ^ (unsigned)(64 * t); wl[t][1] = lb1 ^ (unsigned)(64 * t); }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int it = 3 * w + i;  // this wave's narrow tiles straddle the sub-images
-    nl[i][0] = (unsigned)((NARROW0 + (it >> 2)) * 4096) + (lb0 ^ (unsigned)(64 * (it & 3)));
-    nl[i][1] = (unsigned)((NARROW0 + (it >> 2)) * 4096) + (lb1 ^ (unsigned)(64 * (it & 3)));
-  }
+  for (int i = 0; i < 3; ++i) { const int it = 3 * w + i; lcn[i] = lc + (unsigned)((NARROW0 + (it >> 2)) * 4096 + (it & 3) * 256); }
+  unsigned cur[2][4];  // read addresses of the quarter being prefetched: [q & 1][wide | narrow tile 0..2] = its slot + the constants above
 
   f32x16 accA[16], accV[8];  // tile t = 3 j + i: t < 16 in AGPRs, the rest in VGPRs
 #pragma unroll
@@ -143,7 +144,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tnb_kernel(TnArgs g) {
     constexpr int t = decltype(t_)::v;
     const bf16x8 av = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
     const bf16x8 bv = __builtin_bit_cast(bf16x8, make_uint4(b0.x, b0.y, b1.x, b1.y));
-    if constexpr (t < 16) { f32x16& acc = accA[t]; asm volatile(MFMA32_ASM " %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv)); }
+    if constexpr (TNB_ABL & 2) asm volatile("" ::"v"(av), "v"(bv));
+    else if constexpr (t < 16) { f32x16& acc = accA[t]; asm volatile(MFMA32_ASM " %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv)); }
     else { f32x16& acc = accV[t - 16]; asm volatile(MFMA32_ASM " %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv)); }
   };
   auto dot4 = [&](float& s, const uint2& x0, const uint2& x1) {  // s += the 8 values of a fragment (v_dot2c against (1, 1), f32 accumulate)
@@ -152,53 +154,73 @@ __global__ __launch_bounds__(256, 1) void gemm_tnb_kernel(TnArgs g) {
     asm volatile(DOT2C_F32_16 " %0, %1, %2" : "+v"(s) : "v"(x1.x), "v"(ones2));
     asm volatile(DOT2C_F32_16 " %0, %1, %2" : "+v"(s) : "v"(x1.y), "v"(ones2));
   };
+  auto rd_wide = [&](auto j_, auto h_, unsigned addr) {   // half h of wide fragment j from the quarter at `addr`
+    constexpr int j = decltype(j_)::v, h = decltype(h_)::v;
+    tnb_rd<(WIDE0 + (j >> 2)) * 4096 + h * 1024 + (j & 3) * 256>(fw[j][h], addr);
+  };
 
   // ---- prologue: quarters 0 .. 5 in flight, 0 .. 2 landed (phase 0 reads the fragments of quarters 0, 1 and 2)
   const int npro = nq < 6 ? nq : 6;
   for (int q = 0; q < npro; ++q) { tn_for<0, 5>([&](auto s_) { stage_piece(s_); }); stage_advance(); }
   if (nq >= 6) TNB_WAIT_VM(15); else TNB_WAIT_VM(0);
   TNB_BAR();
-  tn_for<0, 3>([&](auto i_) { constexpr int i = decltype(i_)::v; TNB_DSRD(fn[0][i][0], lds0, nl[i][0], 0); TNB_DSRD(fn[0][i][1], lds0, nl[i][1], 0); });
-  tn_for<0, 8>([&](auto j_) {
-    constexpr int j = decltype(j_)::v; constexpr int IMM = (WIDE0 + (j >> 2)) * 4096;
-    TNB_DSRD(fw[j][0], lds0, wl[j & 3][0], IMM); TNB_DSRD(fw[j][1], lds0, wl[j & 3][1], IMM);
-  });
-  int sr_slot = 1;                 // ring slot of quarter q + 1 (the fragment prefetch target)
-  unsigned sq = lds0 + QB;         // and its LDS address
+  {
+    const unsigned a0 = lds0 + lc;
+    tn_for<0, 3>([&](auto i_) { constexpr int i = decltype(i_)::v; const unsigned an = lds0 + lcn[i]; tnb_rd<0>(fn[0][i][0], an); tnb_rd<1024>(fn[0][i][1], an); });
+    tn_for<0, 8>([&](auto j_) { rd_wide(j_, TnIC<0>{}, a0); rd_wide(j_, TnIC<1>{}, a0); });
+  }
+  int sr_slot = 1;  // ring slot of quarter q + 1 (the fragment prefetch target)
+  cur[0][0] = lds0 + QB + lc;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) cur[0][1 + i] = lds0 + QB + lcn[i];
 
   auto quarter = [&](auto u_, auto more_) {
     constexpr int u = decltype(u_)::v; constexpr bool MORE = decltype(more_)::v != 0;
-    tn_for<0, 3>([&](auto i_) { constexpr int i = decltype(i_)::v; TNB_DSRD(fn[u ^ 1][i][0], sq, nl[i][0], 0); TNB_DSRD(fn[u ^ 1][i][1], sq, nl[i][1], 0); });
+    constexpr bool RD = !(TNB_ABL & 4);
     tn_for<0, 8>([&](auto j_) {
-      constexpr int j = decltype(j_)::v; constexpr int IMM = (WIDE0 + (j >> 2)) * 4096;
-      TNB_WAIT_LGKM(15);
+      constexpr int j = decltype(j_)::v;
+      if constexpr (j == 0) TNB_WAIT_LGKM(8); else if constexpr (j == 4) TNB_WAIT_LGKM(12);
       tn_for<0, 3>([&](auto i_) {
         constexpr int i = decltype(i_)::v;
         if constexpr (WB) mma(TnIC<3 * j + i>{}, fn[u][i][0], fn[u][i][1], fw[j][0], fw[j][1]);
         else mma(TnIC<3 * j + i>{}, fw[j][0], fw[j][1], fn[u][i][0], fn[u][i][1]);
-        if constexpr (MORE && i == 0 && j >= 1 && j <= 5) stage_piece(TnIC<j - 1>{});
+        // ---- the gap behind MFMA i of triple j
+        if constexpr (RD) {
+          if constexpr (j == 0) { tnb_rd<0>(fn[u ^ 1][i][0], cur[u][1 + i]); tnb_rd<1024>(fn[u ^ 1][i][1], cur[u][1 + i]); }
+          else if constexpr (i < 2) rd_wide(TnIC<(j >= 1 ? j - 1 : 0)>{}, i_, cur[u][0]);
+          else if constexpr (j == 7) { rd_wide(TnIC<7>{}, TnIC<0>{}, cur[u][0]); rd_wide(TnIC<7>{}, TnIC<1>{}, cur[u][0]); }
+        }
+        if constexpr (MORE && i == 2 && j >= 1 && j <= 5) stage_piece(TnIC<(j >= 1 && j <= 5 ? j - 1 : 0)>{});
+        if constexpr (i == 2 && j == 6) {  // the next quarter prefetches from the next slot
+          sr_slot = sr_slot == R - 1 ? 0 : sr_slot + 1;
+          const unsigned sq = lds0 + (unsigned)sr_slot * QB;
+          cur[u ^ 1][0] = sq + lc;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) cur[u ^ 1][1 + k] = sq + lcn[k];
+        }
       });
       if constexpr (CS) {
         if constexpr (WB) { if (do_cs && w == (j >> 1)) dot4(cs[j & 1], fw[j][0], fw[j][1]); }        // every wave holds all of B: wave w sums tiles 2w, 2w+1
-        else { if (do_cs && j < 3) dot4(cs[j], fn[u][j][0], fn[u][j][1]); }                            // the wave's own three B tiles, one per MFMA triple
+        else if constexpr (j < 3) { if (do_cs) dot4(cs[j], fn[u][j][0], fn[u][j][1]); }                // the wave's own three B tiles, one per MFMA triple
       }
-      TNB_DSRD(fw[j][0], sq, wl[j & 3][0], IMM); TNB_DSRD(fw[j][1], sq, wl[j & 3][1], IMM);   // wide fragment j of quarter q + 1, behind its last MFMA
     });
-    sr_slot = sr_slot == R - 1 ? 0 : sr_slot + 1; sq = lds0 + (unsigned)sr_slot * QB;
     if constexpr (MORE) stage_advance();
   };
 
   const int P = nq >> 1, Pm = nq >= 8 ? (nq - 6) >> 1 : 0;  // phases; those that still stage two quarters (2p + 7 <= nq - 1)
+  in_loop = true;
   for (int p = 0; p < Pm; ++p) {
     quarter(TnIC<0>{}, TnIC<1>{}); quarter(TnIC<1>{}, TnIC<1>{});
-    TNB_WAIT_VM(15);  // this wave's pieces of quarters <= 2p + 4 have landed (three quarters = 15 pieces may still be in flight)
-    TNB_BAR();        // ... and everyone's; every wave has left the two slots the next phase refills
+    if constexpr (!(TNB_ABL & 8)) {
+      TNB_WAIT_VM(15);  // this wave's pieces of quarters <= 2p + 4 have landed (three quarters = 15 pieces may still be in flight)
+      TNB_BAR();        // ... and everyone's; every wave has left the two slots the next phase refills
+    }
   }
   for (int p = Pm; p < P; ++p) {
     quarter(TnIC<0>{}, TnIC<0>{}); quarter(TnIC<1>{}, TnIC<0>{});
-    TNB_WAIT_VM(0);
-    TNB_BAR();
+    if constexpr (!(TNB_ABL & 8)) { TNB_WAIT_VM(0); TNB_BAR(); }
   }
+  TNB_WAIT_VM(0);
   TNB_WAIT_LGKM(0);  // the last quarter's prefetch reads (unused) must have returned before their registers are reused
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA results -> VALU reads: the compiler cannot see the producers
 

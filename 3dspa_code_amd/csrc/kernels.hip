@@ -1505,23 +1505,22 @@ __device__ __forceinline__ float log_sigmoid_f(float x) { return fminf(x, 0.f) -
 // on arrival order (the same batch gave 14089.21875 and 14089.216796875 in round 3), so two data-parallel replicas could log different
 // losses and a test could not ask for bit-equal reruns.  Each workgroup reduces in a fixed order and adds its partial as a 64-bit FIXED-POINT
 // integer (2^-24 units: exact, order-independent integer addition; quantisation 6e-8 per workgroup, far below fp32 resolution of the sums).
-// Layout of the 8-float `sums` block: three 64-bit accumulators {position numerator, bce numerator, visible count} | denominator | loss scale.
-// A partial that is not finite or beyond the fixed-point range poisons its accumulator (top bit pattern LOSS_POISON -> the sum reads as NaN).
+// Layout of the 10-float `sums` block: three 64-bit accumulators {position numerator, bce numerator, visible count} | denominator | loss scale | flag word.
+// A partial that is not finite or beyond the fixed-point range sets a STICKY flag word (atomicOr) next to the accumulators and adds nothing; the sums then read as
+// NaN.  (Round 4 added a marker value to the accumulator itself: k marked workgroups sum to k * 2^62 mod 2^64 = 0 for 4 | k, so a fully diverged forward reported loss 0.)
 constexpr float LOSS_FIX = 16777216.f;                 // 2^24
-constexpr long long LOSS_POISON = 0x4000000000000000ll;  // > any legitimate sum: 4096 workgroups x 2^50
-__device__ __forceinline__ void loss_acc_add(unsigned long long* acc, float partial) {
+__device__ __forceinline__ void loss_acc_add(unsigned long long* acc, unsigned* poison, float partial) {
   const float f = partial * LOSS_FIX;
-  long long q = (fabsf(f) < 1.0e15f) ? __float2ll_rn(f) : LOSS_POISON;   // NaN fails the comparison too
-  atomicAdd(acc, (unsigned long long)q);
+  if (fabsf(f) < 1.0e15f) atomicAdd(acc, (unsigned long long)__float2ll_rn(f));   // NaN fails the comparison too
+  else atomicOr(poison, 1u);
 }
-__device__ __forceinline__ float loss_acc_read(const unsigned long long* acc) {
-  const long long q = (long long)*acc;
-  if (q >= LOSS_POISON / 2 || q <= -LOSS_POISON / 2) return __int_as_float(0x7fc00000);
-  return (float)((double)q * (1.0 / 16777216.0));
+__device__ __forceinline__ float loss_acc_read(const unsigned long long* acc, const unsigned* poison) {
+  if (*poison) return __int_as_float(0x7fc00000);
+  return (float)((double)(long long)*acc * (1.0 / 16777216.0));
 }
 __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const float* __restrict__ head, int64_t nq, int T_, const float* __restrict__ tgt,
                                                             const float* __restrict__ tvis, float* __restrict__ tracks,
-                                                            float* __restrict__ vlog, float* __restrict__ clog, float* __restrict__ sums, int NC) {
+                                                            float* __restrict__ vlog, float* __restrict__ clog, float* __restrict__ sums, unsigned* poison, int NC) {
   // head row: NC coordinate blocks of T, then the visibility logits; the 2-D model (NC == 2) has a 4th block: certainty logits
   __shared__ float red[3][4];
   float pn = 0.f, bn = 0.f;
@@ -1550,20 +1549,20 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(const float* __restr
   if ((threadIdx.x & 63) == 0) { red[0][w] = pn; red[1][w] = bn; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    loss_acc_add((unsigned long long*)sums + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-    loss_acc_add((unsigned long long*)sums + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    loss_acc_add((unsigned long long*)sums + 0, poison, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    loss_acc_add((unsigned long long*)sums + 1, poison, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
   }
 }
 void k_loss_fwd(spa3d_ctx* c, const float* head, int64_t nq, int T_, const float* tgt, const float* tvis, float* tracks, float* vlog,
-                float* clog, float* sums, int NC) {
+                float* clog, float* sums, unsigned* poison, int NC) {
   if (c->dry || nq == 0) return;
   unsigned g = (unsigned)std::min<int64_t>(cdiv(nq * T_, 256), 4096);
-  head_loss_fwd_kernel<<<g, 256, 0, c->stream>>>(head, nq, T_, tgt, tvis, tracks, vlog, clog, sums, NC);
+  head_loss_fwd_kernel<<<g, 256, 0, c->stream>>>(head, nq, T_, tgt, tvis, tracks, vlog, clog, sums, poison, NC);
   SPA_LAUNCH_CHECK(c);
 }
 // same numerators from already-split predictions (spa3d_loss entry point)
 __global__ __launch_bounds__(256) void loss_from_preds_kernel(const float* __restrict__ tracks, const float* __restrict__ vlog, int64_t n,
-                                                              const float* __restrict__ tgt, const float* __restrict__ tvis, float* sums, int NC) {
+                                                              const float* __restrict__ tgt, const float* __restrict__ tvis, float* sums, unsigned* poison, int NC) {
   __shared__ float red[2][4];
   float pn = 0.f, bn = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -1578,47 +1577,47 @@ __global__ __launch_bounds__(256) void loss_from_preds_kernel(const float* __res
   if ((threadIdx.x & 63) == 0) { red[0][w] = pn; red[1][w] = bn; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    loss_acc_add((unsigned long long*)sums + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-    loss_acc_add((unsigned long long*)sums + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    loss_acc_add((unsigned long long*)sums + 0, poison, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    loss_acc_add((unsigned long long*)sums + 1, poison, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
   }
 }
 void k_loss_from_preds(spa3d_ctx* c, const float* tracks, const float* vlog, int64_t n, const float* tgt, const float* tvis, float* sums,
-                       int NC) {
+                       unsigned* poison, int NC) {
   if (c->dry || n == 0) return;
   unsigned g = (unsigned)std::min<int64_t>(cdiv(n, 256), 4096);
-  loss_from_preds_kernel<<<g, 256, 0, c->stream>>>(tracks, vlog, n, tgt, tvis, sums, NC);
+  loss_from_preds_kernel<<<g, 256, 0, c->stream>>>(tracks, vlog, n, tgt, tvis, sums, poison, NC);
   SPA_LAUNCH_CHECK(c);
 }
-__global__ __launch_bounds__(256) void vis_count_kernel(const float* __restrict__ v, int64_t n, float* out) {
+__global__ __launch_bounds__(256) void vis_count_kernel(const float* __restrict__ v, int64_t n, float* out, unsigned* poison) {
   __shared__ float red[4];
   float s = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += v[i];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) loss_acc_add((unsigned long long*)out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) loss_acc_add((unsigned long long*)out, poison, red[0] + red[1] + red[2] + red[3]);
 }
-void k_vis_count(spa3d_ctx* c, const float* tvis, int64_t n, float* out) {
+void k_vis_count(spa3d_ctx* c, const float* tvis, int64_t n, float* out, unsigned* poison) {
   if (c->dry || n == 0) return;
   unsigned g = (unsigned)std::min<int64_t>(cdiv(n, 256), 1024);
-  vis_count_kernel<<<g, 256, 0, c->stream>>>(tvis, n, out); SPA_LAUNCH_CHECK(c);
+  vis_count_kernel<<<g, 256, 0, c->stream>>>(tvis, n, out, poison); SPA_LAUNCH_CHECK(c);
 }
 // sums = {pos_num, bce_num, vis_cnt} (fixed-point accumulators, see loss_acc_add); denom_dev = denom_host>0 ? denom_host : max(vis_cnt,1)
-__global__ void set_denom_kernel(const float* sums, float denom_host, float* denom_dev) {
-  *denom_dev = denom_host > 0.f ? denom_host : fmaxf(loss_acc_read((const unsigned long long*)sums + 2), 1.f);
+__global__ void set_denom_kernel(const float* sums, const unsigned* poison, float denom_host, float* denom_dev) {
+  *denom_dev = denom_host > 0.f ? denom_host : fmaxf(loss_acc_read((const unsigned long long*)sums + 2, poison), 1.f);  // fmaxf(NaN, 1) = 1: the numerators carry the NaN
 }
-void k_set_denom(spa3d_ctx* c, const float* sums, float denom_host, float* denom_dev) {
+void k_set_denom(spa3d_ctx* c, const float* sums, const unsigned* poison, float denom_host, float* denom_dev) {
   if (c->dry) return;
-  set_denom_kernel<<<1, 1, 0, c->stream>>>(sums, denom_host, denom_dev); SPA_LAUNCH_CHECK(c);
+  set_denom_kernel<<<1, 1, 0, c->stream>>>(sums, poison, denom_host, denom_dev); SPA_LAUNCH_CHECK(c);
 }
-__global__ void loss_finalize_kernel(const float* sums, const float* denom_dev, float l1w, float bcew, float* loss3) {
+__global__ void loss_finalize_kernel(const float* sums, const unsigned* poison, const float* denom_dev, float l1w, float bcew, float* loss3) {
   float d = *denom_dev;
-  float pos = loss_acc_read((const unsigned long long*)sums + 0) / d, vis = loss_acc_read((const unsigned long long*)sums + 1) / d;
+  float pos = loss_acc_read((const unsigned long long*)sums + 0, poison) / d, vis = loss_acc_read((const unsigned long long*)sums + 1, poison) / d;
   loss3[0] = l1w * pos + bcew * vis; loss3[1] = pos; loss3[2] = vis;
 }
-void k_loss_finalize(spa3d_ctx* c, const float* sums, const float* denom_dev, float l1w, float bcew, float* loss3) {
+void k_loss_finalize(spa3d_ctx* c, const float* sums, const unsigned* poison, const float* denom_dev, float l1w, float bcew, float* loss3) {
   if (c->dry) return;
-  loss_finalize_kernel<<<1, 1, 0, c->stream>>>(sums, denom_dev, l1w, bcew, loss3); SPA_LAUNCH_CHECK(c);
+  loss_finalize_kernel<<<1, 1, 0, c->stream>>>(sums, poison, denom_dev, l1w, bcew, loss3); SPA_LAUNCH_CHECK(c);
 }
 // d head: l1w*sign(pred-tgt)*vis/denom ; bcew*(sigmoid(l)-y)/denom ; sign(0)=0
 template <typename T>

@@ -765,9 +765,10 @@ void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
   const bool train = a.mode == MODE_TRAIN;
   Net<T> net(c, a.P, a.G);
   net.pack();
-  float* sums = net.template alloc<float>(8);
-  float* denom_dev = sums + 6;  // [0..5] three 64-bit fixed-point accumulators (kernels.hip loss_acc_add), [6] denominator, [7] loss scale
-  k_zero(c, sums, 32);
+  float* sums = net.template alloc<float>(10);
+  float* denom_dev = sums + 6;  // [0..5] three 64-bit fixed-point accumulators (kernels.hip loss_acc_add), [6] denominator, [7] loss scale, [8] sticky non-finite flag
+  unsigned* poison = (unsigned*)(sums + 8);
+  k_zero(c, sums, 40);
   const float* noise = b->noise;
   if (a.mode != MODE_ENCODE && b->discretize && !noise) {
     float* nb = net.template alloc<float>((int64_t)b->B * L * Ld);
@@ -775,8 +776,8 @@ void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
     noise = nb;
   }
   if (train) {
-    k_vis_count(c, b->query_tracks_visible, (int64_t)b->B * b->Q * To, sums + 4);
-    k_set_denom(c, sums, a.denom, denom_dev);
+    k_vis_count(c, b->query_tracks_visible, (int64_t)b->B * b->Q * To, sums + 4, poison);
+    k_set_denom(c, sums, poison, a.denom, denom_dev);
     if (c->loss_scale != 1.f) k_set_loss_scale(c, denom_dev, L1_WEIGHT, c->loss_scale, denom_dev + 1);  // sums[7]
     if (!a.accumulate) k_zero(c, a.G, c->nparams * 4);
   }
@@ -806,13 +807,13 @@ void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
       float* vl = a.out && a.out->visible_logits ? a.out->visible_logits + b0 * b->Q * To : nullptr;
       float* cl = a.out && a.out->certain_logits ? a.out->certain_logits + b0 * b->Q * To : nullptr;
       k_loss_fwd(c, k.head, nq, To, train ? b->query_tracks + b0 * b->Q * To * NC : nullptr,
-                 train ? b->query_tracks_visible + b0 * b->Q * To : nullptr, tr, vl, cl, sums, NC);
+                 train ? b->query_tracks_visible + b0 * b->Q * To : nullptr, tr, vl, cl, sums, poison, NC);
       if (train) net.backward_chunk(k, b, b0, denom_dev);
     }
     c->ar.release(mk);
   }
   if (train && c->loss_scale != 1.f) k_unscale(c, a.G, denom_dev + 1, c->nparams);  // fp32 gradient buffer back to true scale (exact: power of two)
-  if (train && a.loss3) k_loss_finalize(c, sums, denom_dev, L1_WEIGHT, BCE_WEIGHT, a.loss3);
+  if (train && a.loss3) k_loss_finalize(c, sums, poison, denom_dev, L1_WEIGHT, BCE_WEIGHT, a.loss3);
 }
 
 // entry points of this build's 16-bit type (and of the fp32 parity path, which lives in the bf16 build only)
@@ -1032,13 +1033,14 @@ int spa3d_loss(spa3d_handle h, const spa3d_batch* b, const spa3d_outputs* preds,
     return SPA3D_ERR_ARG;
   h->err.clear(); h->hip_err = 0; h->stream = (hipStream_t)stream; h->dry = false;
   if (((uintptr_t)loss3) & 7) { h->err = "loss3 must be 8-byte aligned"; return SPA3D_ERR_ARG; }
-  float* scratch = loss3 + 4;  // loss3 points at 12 floats: [0..2] results, [4..9] three 64-bit fixed-point accumulators, [10] denominator
+  float* scratch = loss3 + 4;  // loss3 points at 12 floats: [0..2] results, [3] sticky non-finite flag, [4..9] three 64-bit fixed-point accumulators, [10] denominator
+  unsigned* poison = (unsigned*)(loss3 + 3);
   const int64_t n = (int64_t)b->B * b->Q * h->cfg.num_output_frames;
-  k_zero(h, scratch, 32);
-  k_vis_count(h, b->query_tracks_visible, n, scratch + 4);
-  k_set_denom(h, scratch, denom, scratch + 6);
-  k_loss_from_preds(h, preds->tracks, preds->visible_logits, n, b->query_tracks, b->query_tracks_visible, scratch, h->cfg.model_kind == 1 ? 2 : 3);
-  k_loss_finalize(h, scratch, scratch + 6, L1_WEIGHT, BCE_WEIGHT, loss3);
+  k_zero(h, loss3 + 3, 36);
+  k_vis_count(h, b->query_tracks_visible, n, scratch + 4, poison);
+  k_set_denom(h, scratch, poison, denom, scratch + 6);
+  k_loss_from_preds(h, preds->tracks, preds->visible_logits, n, b->query_tracks, b->query_tracks_visible, scratch, poison, h->cfg.model_kind == 1 ? 2 : 3);
+  k_loss_finalize(h, scratch, poison, scratch + 6, L1_WEIGHT, BCE_WEIGHT, loss3);
   return h->hip_err ? SPA3D_ERR_HIP : SPA3D_OK;
 }
 

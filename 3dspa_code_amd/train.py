@@ -211,8 +211,10 @@ class TrainState:
     self.close()
 
   def sync_from_rank0(self):
-    """parameters + Adam moments of every replica := rank 0's (also after load_train_state on rank 0 only)"""
-    broadcast_state_((self.flat, self.m, self.v), 0, self.pg, self.force)
+    """parameters + Adam moments + optimizer counters of every replica := rank 0's (also after load_train_state on rank 0 only).
+    scratch[3:6] = skipped-update count (enters the Adam bias correction), loss-scale multiplier, its good-step counter: a replica that kept its own
+    would apply a different update after a resume and drift apart silently."""
+    broadcast_state_((self.flat, self.m, self.v, self.scratch[3:6]), 0, self.pg, self.force)
 
   # ---- default (HIP) compute and optimizer
   def _hip_compute(self, params, batch, grads_flat, denom, discretize, noise):

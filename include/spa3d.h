@@ -123,7 +123,8 @@ int spa3d_decode(spa3d_handle h, const float* params, const spa3d_batch* b, cons
 int spa3d_forward(spa3d_handle h, const float* params, const spa3d_batch* b, spa3d_outputs* out,
                   void* ws, int64_t ws_bytes, void* stream);
 
-/* loss3 (device, >= 12 floats, 8-byte aligned: [0..2] = total, position, visible; the rest is scratch).
+/* loss3 (device, >= 12 floats, 8-byte aligned: [0..2] = total, position, visible; the rest is scratch -- [3] a sticky flag word
+ * that any non-finite partial sum sets, after which all three results are NaN).
  * denom<=0: use max(sum(visible),1) of this batch.  The batch sums are order-independent (64-bit fixed-point accumulation): the same
  * inputs give the same bits on every run and on every data-parallel replica. */
 int spa3d_loss(spa3d_handle h, const spa3d_batch* b, const spa3d_outputs* preds, float denom,

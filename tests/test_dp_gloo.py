@@ -188,3 +188,67 @@ def test_trainstate_step_world2_equals_full_batch():
   for a, b in zip(losses, ref_losses):
     assert abs(a - b) < 1e-5 * abs(b)
   assert abs(gn - gn_ref) < 1e-4 * gn_ref
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# resume under data parallelism: the optimizer counters travel with the state
+# ---------------------------------------------------------------------------------------------------------------------
+def _resume_worker(rank, world, port, q, path):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    import spa3d
+    from util import product_model
+    torch.set_num_threads(2)
+    cfg = O.Config(**MINI, use_dino=False, use_depth=False)
+    B = 4
+    batch = O.synthetic_batch(B, 5, 4, 8, seed=23)
+    model = product_model(spa3d, cfg, 'fp32')
+    params = O.init_params(cfg, seed=9 + rank, dtype=torch.float32, with_dino=False, with_depth=False, perturb=0.1)
+    _, leaves, n = model._handle(0, 0)
+    compute, _, noise_fn = _oracle_hooks(cfg, leaves)
+
+    def adamw(flat, grads, mm, vv, lr, step, clip, b1, b2, eps, wd, scratch):  # the HIP kernel's rule: bias correction counts APPLIED updates (spa3d.h)
+      gn = O.adamw_step({'p': flat}, {'p': grads}, {'p': mm}, {'p': vv}, step - int(scratch[3]), lr, clip=clip, wd=wd, b1=b1, b2=b2, eps=eps)
+      scratch[0] = gn
+
+    mk = lambda p: spa3d.TrainState(model, p, learning_rate=1e-2, warmup_steps=1, total_steps=10, grad_bucket_bytes=4000, compute=compute, adamw=adamw,
+                                    noise_fn=noise_fn)
+    s0 = mk(params)  # (every rank constructs it: the constructor broadcasts rank 0's buffers, a collective)
+    if rank == 0:  # a state that has made 5 calls of which 2 were skipped, with a halved loss-scale multiplier
+      s0.step = 5; s0.m.normal_(generator=torch.Generator().manual_seed(1)).mul_(1e-3); s0.v.uniform_(1e-6, 1e-5, generator=torch.Generator().manual_seed(2))
+      s0.scratch[3:6] = torch.tensor([2.0, 0.5, 7.0])
+      spa3d.save_checkpoint(path, s0.params, s0)
+    dist.barrier()
+    st = mk(O.init_params(cfg, seed=40 + rank, dtype=torch.float32, with_dino=False, with_depth=False, perturb=0.1))
+    spa3d.load_train_state(path, st, rank0_only=True)   # rank 1 never opens the file
+    counters = [float(x) for x in st.scratch[3:6]]
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    st.train_step({k: v[lo:hi] for k, v in batch.items()})
+    import hashlib  # (digests, not arrays: the parent joins before it drains the queue, and a pipe-sized payload would block the put)
+    dg = lambda t: hashlib.sha256(t.detach().cpu().numpy().tobytes()).hexdigest()
+    q.put((rank, st.step, counters, dg(st.flat), dg(st.m), float(st.flat.double().abs().sum())))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_dp_resume_carries_the_optimizer_counters_to_every_rank(tmp_path):
+  ctx = mp.get_context('spawn')
+  q = ctx.SimpleQueue()
+  port = _free_port()
+  path = str(tmp_path / 'state.npz')
+  procs = [ctx.Process(target=_resume_worker, args=(r, 2, port, q, path)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = []
+  for p in procs:
+    p.join(300)
+    if p.is_alive():
+      p.kill()
+    assert p.exitcode == 0, f'worker exit code {p.exitcode}'
+  res = sorted([q.get(), q.get()], key=lambda r: r[0])
+  for r in res:
+    assert r[1] == 6 and r[2] == [2.0, 0.5, 7.0], r[1:3]   # step and scratch[3:6] on BOTH ranks (rank 1 got them by broadcast)
+  assert res[0][3] == res[1][3] and res[0][4] == res[1][4], 'replicas diverged after one step from a resumed state'
+  assert res[0][5] > 0.0

@@ -10,6 +10,8 @@ the reference, which cannot run."""
 import os
 import sys
 
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -133,6 +135,37 @@ def test_bf16_nan_gradients_skip_the_update_and_check_finite_raises():
   m2 = st.train_step(gb, noise=noise.cuda())  # a clean batch trains on
   assert float(m2['train/skipped']) == 0.0
   st.check_finite()
+
+
+@pytest.mark.gpu
+def test_a_fully_diverged_forward_reports_nan_not_zero():
+  """the non-finite marker of the fixed-point loss sums must be sticky.  Round 4 ADDED a 2^62 marker per poisoned workgroup, so k poisoned workgroups
+  summed to k * 2^62 mod 2^64 = 0 whenever 4 | k and a fully diverged forward (every partial NaN, 4096 workgroups) reported loss 0.0 where the reference logs NaN
+  (train.py:96-129 on NaN predictions).  Both paths: spa3d_loss (loss_from_preds) and the train path's head kernel."""
+  import spa3d
+  B, Q, T = 4, 512, 600   # B Q T / 256 = 4800 -> the grid is capped at 4096 workgroups, a multiple of 4
+  g = torch.Generator().manual_seed(5)
+  tgt = {'query_tracks': torch.rand(B, Q, T, 3, generator=g).cuda(), 'query_tracks_visible': (torch.rand(B, Q, T, 1, generator=g) < 0.9).float().cuda()}
+  nan = spa3d.TrackAutoEncoderResults(tracks=torch.full((B, Q, T, 3), float('nan'), device='cuda'),
+                                      visible_logits=torch.full((B, Q, T, 1), float('nan'), device='cuda'), certain_logits=torch.zeros(B, Q, T, 1, device='cuda'))
+  ld = spa3d.compute_loss_3d(nan, tgt)
+  assert all(math.isnan(float(ld[k])) for k in ('total_loss', 'position_loss', 'visible_loss')), {k: float(v) for k, v in ld.items()}
+  # one NaN element among finite ones is enough, and a finite batch stays finite
+  ok = spa3d.TrackAutoEncoderResults(tracks=torch.rand(B, Q, T, 3, generator=g).cuda(), visible_logits=torch.randn(B, Q, T, 1, generator=g).cuda(),
+                                     certain_logits=torch.zeros(B, Q, T, 1, device='cuda'))
+  assert math.isfinite(float(spa3d.compute_loss_3d(ok, tgt)['total_loss']))
+  ok.tracks[1, 7, 3, 2] = float('inf')
+  assert math.isnan(float(spa3d.compute_loss_3d(ok, tgt)['position_loss']))
+  # train path: NaN parameters -> every head value NaN -> train/loss must be NaN (head_loss_fwd_kernel)
+  cfg, batch, noise = _small_full_model_case()
+  gb = batch_to(batch, 'cuda')
+  for k in ('dino_features', 'depth_features'):
+    gb[k] = gb[k].bfloat16()
+  model = product_model(spa3d, cfg, 'bf16')
+  params = model.init(0, gb)['params']
+  bad = O.tree_map(lambda t: torch.full_like(t, float('nan')), params)
+  ld, _, _ = model.loss_and_grads({'params': bad}, gb, noise=noise.cuda())
+  assert math.isnan(float(ld['total_loss'])), float(ld['total_loss'])
 
 
 @pytest.mark.gpu
