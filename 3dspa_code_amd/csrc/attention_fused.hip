@@ -577,7 +577,7 @@ struct AttnBwdArgs {
   // cross attention (attn_bwd8_kernel<8, true>): S = query rows per sequence (<= 128); the Sk keys of a sequence are cut into nsplit chunks
   // of 128, one workgroup pass per (sequence, head, chunk); dq^ (before the RMSNorm backward) leaves as fp32 partials per chunk
   int Sk, nsplit; float* dqpart;  // [nprob][nsplit][S][96]
-#ifdef SPA3D_ABLATE  // tools/ablate_attn.py builds a separate diagnostic library with this; never defined for libspa3d_hip.so
+#if SPA3D_ABL_ATTN  // tools/ablate_attn.py builds a separate diagnostic library with this; never defined for libspa3d_hip.so
   int ablate;          // 1: no tile work, 2: no staging (garbage operands), 4: no dq/dk/dv stores
 #endif
 };
@@ -594,7 +594,7 @@ __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, c
                                                const mfma16x8 (&qb)[3], const mfma16x8 (&dob)[3], float mq, float lq, float dq_,
                                                const u16x4 (&xraw)[6], bool valid, char* wt, bf16_t* gtile, int64_t ld_, int nrows,
                                                float (&ds_acc)[6][4], float* dqp = nullptr
-#ifdef SPA3D_ABLATE
+#if SPA3D_ABL_ATTN
                                                , int ablate = 0
 #endif
                                                ) {
@@ -604,7 +604,7 @@ __device__ __forceinline__ void bwd_query_tile(const char* Ks, const char* Vs, c
   mfma16x8 dsb[NPAIR];
 #pragma unroll
   for (int s2 = 0; s2 < NPAIR; ++s2) {
-#ifdef SPA3D_ABLATE
+#if SPA3D_ABL_ATTN
     if (ablate & 8) {  // what a dS tile handed over through LDS would cost this role: one 16-byte read per key-tile pair, no S / dP work
       dsb[s2] = *(const mfma16x8*)(Vs + 2 * s2 * ROW16 + row_off(fr) + fq * 16);
       continue;
@@ -906,7 +906,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
     constexpr int NP = (S_pad + 127) / 128;
     // all five matrices of the problem are requested before the first is used: one memory latency per problem
     RawRows<NP> rq, rk, rv, rd, ro;
-#ifdef SPA3D_ABLATE
+#if SPA3D_ABL_ATTN
     if (!(g.ablate & 2)) {
 #endif
     const int tid_o = opaque_tid();  // per-problem copy: the row offsets below are recomputed, not hoisted out of the loop and spilled (rows_load)
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
     rows_store<true, NP, 128>(rk, S_pad, sscale + DH, Ks);
     rows_store<false, NP, 128>(rv, S_pad, nullptr, Vs);
     store_do_delta<NP, 128, FAST>(rd, ro, S_pad, dOs, drow);  // FAST: -delta
-#ifdef SPA3D_ABLATE
+#if SPA3D_ABL_ATTN
     }
 #endif
     for (int t = tid; t < S_pad; t += 512) {
@@ -933,7 +933,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
       else { mrow[t] = m; lrow[t] = ll; }
     }
     __syncthreads();
-#ifdef SPA3D_ABLATE
+#if SPA3D_ABL_ATTN
     if (g.ablate & 1) continue;
 #endif
 
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
           qb[s] = *(const mfma16x8*)(Qs + qt * ROW16 + row_off(fr) + (s * 32 + fq * 8) * 2);
           dob[s] = *(const mfma16x8*)(dOs + qt * ROW16 + row_off(fr) + (s * 32 + fq * 8) * 2);
         }
-#ifdef SPA3D_ABLATE
+#if SPA3D_ABL_ATTN
         const int nrows_st = (g.ablate & 4) ? 0 : S - q0;
 #else
         const int nrows_st = S - q0;
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
         bwd_query_tile<KT, X, FAST>(Ks, Vs, kbias, sscale, qb, dob, mrow[q0 + fr], lrow[q0 + fr], drow[q0 + fr], xraw, valid, wt,
                               g.dq + (row0 + q0) * g.ldq + h * DH, g.ldq, nrows_st, ds_acc,
                               X ? g.dqpart + ((pi * g.S) + q0) * DH : nullptr
-#ifdef SPA3D_ABLATE
+#if SPA3D_ABL_ATTN
                               , g.ablate
 #endif
                               );
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
           kb[s] = *(const mfma16x8*)(Ks + kt * ROW16 + row_off(fr) + (s * 32 + fq * 8) * 2);
           vb[s] = *(const mfma16x8*)(Vs + kt * ROW16 + row_off(fr) + (s * 32 + fq * 8) * 2);
         }
-#ifdef SPA3D_ABLATE
+#if SPA3D_ABL_ATTN
         const int nrows_st = (g.ablate & 4) ? 0 : Sk - k0;
 #else
         const int nrows_st = Sk - k0;
@@ -1184,7 +1184,7 @@ bool attn_fused_bwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const b
       AttnBwdArgs a; a.q = q; a.k = k; a.v = v; a.o = o; a.d_o = d_o; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.sq = sq; a.sk = sk; a.km = km;
       a.lse = lse; a.S = Sq; a.H = H; a.nprob = nprob; a.dq = dq; a.dk = dk; a.dv = dv; a.dsq = dsq; a.dsk = dsk; a.seq_off = nullptr;
       a.Sk = Sk; a.nsplit = nsplit; a.dqpart = dqpart;
-#ifdef SPA3D_ABLATE
+#if SPA3D_ABL_ATTN
       a.ablate = 0;
 #endif
       ProfScope ps(c, PROF_ATTN_BWD, 14.0 * (double)nprob * Sq * Sk * DH, (double)nprob * (4.0 * Sq + 4.0 * Sk) * DH * 2.0);
@@ -1210,7 +1210,7 @@ bool attn_fused_bwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const b
   a.lse = lse; a.S = Sk; a.H = H; a.nprob = nseq * H; a.dq = dq; a.dk = dk; a.dv = dv; a.dsq = dsq; a.dsk = dsk; a.seq_off = seq_off;
   a.Sk = Sk; a.nsplit = 1; a.dqpart = nullptr;
   const double rows = total_rows > 0 ? (double)total_rows : (double)nseq * Sk;
-#ifdef SPA3D_ABLATE
+#if SPA3D_ABL_ATTN
   { const char* e = getenv("SPA3D_ABLATE"); a.ablate = e ? atoi(e) : 0; }
 #endif
   // even tile counts only: the tile routines take an odd KT (the last pair half empty, as in the forward's nine-tile instance), but at S = 129 the backward

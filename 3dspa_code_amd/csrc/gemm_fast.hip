@@ -43,7 +43,7 @@ struct NtArgs {
   int64_t M; int N; int K; int64_t lda, ldb, ldc;
   const float* bias; const bf16_t* aux; bf16_t* pre_out; int epi; int out_f32; int accumulate; float alpha;
   int tiles_m, tiles_n, crow_group, crow_skip;
-#ifdef SPA3D_ABLATE
+#if SPA3D_ABL_NT
   int ablate;
 #endif
   // one-pass input embedding (non-persistent 128x384 8-phase kernel only; GemmDesc::A2 ...): K columns [0, K1) come from A, [K1, K) from A2 (row
@@ -428,8 +428,8 @@ __device__ __forceinline__ void nt_store4(const NtArgs& g, int64_t gm, int gn, c
   }
 }
 
-// diagnostic library only (tools/ablate_gemm.py, -DSPA3D_ABLATE): the persistent kernel without its output stores = loop-only time
-#ifdef SPA3D_ABLATE
+// diagnostic library only (tools/ablate_gemm.py, -DSPA3D_ABLATION_BUILD -DSPA3D_ABL_NT=1: csrc/ablate.inc): the persistent kernel without its output stores = loop-only time
+#if SPA3D_ABL_NT
 #define NT_ABLATE_STORES && !g.ablate
 #else
 #define NT_ABLATE_STORES
@@ -989,6 +989,13 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   if (d.bias && !aligned16(d.bias)) return false;
   if (d.pre_out && (!aligned16(d.pre_out) || d.out_f32)) return false;
   if ((int64_t)d.M * d.N < 128 * 128) return false;  // tiny problems: the generic kernel has less tail waste
+  const bool emb = d.A2 || d.arow_idx || d.crow_idx || d.r1_x;
+  if (emb) {  // one-pass input embedding: only the non-persistent 128 x 384 8-phase kernel carries these operands.  Checked BEFORE the dry-run return: the sizing pass
+              // must refuse exactly what the real run refuses, or the caller's fallback allocates buffers the workspace was never sized for
+    if (d.N != 384 || d.out_f32 || d.accumulate || d.aux || d.pre_out || d.epi != EPI_NONE || d.crow_group) return false;
+    if (d.A2 && (d.K1 % 64 || d.K1 <= 0 || d.K1 >= d.K || d.sA2m % 8 || (!c->dry && !aligned16(d.A2)))) return false;
+    if (d.r1_x && !d.r1_w) return false;
+  }
   if (c->dry) return true;
   NtArgs g;
   g.A = (const bf16_t*)d.A; g.Bt = Bt; g.C = d.C; g.M = d.M; g.N = d.N; g.K = d.K; g.lda = d.sAm; g.ldb = ldb; g.ldc = d.sCm;
@@ -996,13 +1003,7 @@ bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d) {
   g.tiles_m = (int)((d.M + 127) / 128); g.tiles_n = (d.N + 127) / 128;
   g.crow_group = d.crow_group; g.crow_skip = d.crow_skip;
   g.A2 = (const bf16_t*)d.A2; g.lda2 = d.sA2m; g.K1 = d.K1; g.arow_idx = d.arow_idx; g.crow_idx = d.crow_idx; g.r1_x = (const bf16_t*)d.r1_x; g.r1_w = d.r1_w;
-  const bool emb = d.A2 || d.arow_idx || d.crow_idx || d.r1_x;
-  if (emb) {  // one-pass input embedding: only the non-persistent 128 x 384 8-phase kernel carries these operands
-    if (d.N != 384 || d.out_f32 || d.accumulate || d.aux || d.pre_out || d.epi != EPI_NONE || d.crow_group) return false;
-    if (d.A2 && (d.K1 % 64 || d.K1 <= 0 || d.K1 >= d.K || d.sA2m % 8 || !aligned16(d.A2))) return false;
-    if (d.r1_x && !d.r1_w) return false;
-  }
-#ifdef SPA3D_ABLATE
+#if SPA3D_ABL_NT
   { const char* e = getenv("SPA3D_ABLATE"); g.ablate = e ? atoi(e) : 0; }
 #endif
   g.nt_store = (!d.out_f32 && (double)d.M * d.N * 2.0 >= 512e6 && c->nt_stream) ? 1 : 0;
@@ -1317,7 +1318,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs g) {
 #pragma unroll
     for (int u = 0; u < QP; ++u) {
 #pragma unroll
-#if defined(SPA3D_TN_ABL) && (SPA3D_TN_ABL & 1)  // diagnostic build only (tools/ablate_gemm_tn.py): half of the transposed reads (WRONG results: timing only)
+#if (SPA3D_ABL_TN & 1)  // diagnostic build only (tools/ablate_gemm_tn.py): half of the transposed reads (WRONG results: timing only)
       for (int j = 0; j < WNT; ++j) { fb[u][j][0] = ds_read_tr16_b64(sq + u * QB + offb[j][0]); fb[u][j][1] = fb[u][j][0]; }
 #pragma unroll
       for (int i = 0; i < WIT; ++i) { fa[u][i][0] = ds_read_tr16_b64(sq + u * QB + offa[i][0]); fa[u][i][1] = fa[u][i][0]; }
@@ -1342,7 +1343,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs g) {
         const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(fa[u][i][0].x, fa[u][i][0].y, fa[u][i][1].x, fa[u][i][1].y));
 #pragma unroll
         for (int j = 0; j < WNT; ++j)
-#if defined(SPA3D_TN_ABL) && (SPA3D_TN_ABL & 2)  // no MFMAs (timing only)
+#if (SPA3D_ABL_TN & 2)  // no MFMAs (timing only)
           asm volatile("" ::"v"(af), "v"(fb[u][j][0]), "v"(fb[u][j][1]));
 #else
           acc[i][j] = MFMA32(af, __builtin_bit_cast(bf16x8, make_uint4(fb[u][j][0].x, fb[u][j][0].y, fb[u][j][1].x, fb[u][j][1].y)), acc[i][j]);

@@ -60,12 +60,9 @@ struct RsArgs {
   int64_t M; int N, nseg, tiles, nt_store;
   unsigned long long* dbg;  // diagnostic builds with mask 32 only: per-wave cycle sums (s_memtime), else unused
 };
-// diagnostic builds only (tools/ablate_gemm_rs.py compiles a SEPARATE library per mask, never the product): compile-time mask, 1 stores wrapped into a 1-MiB window,
+// diagnostic builds only (tools/ablate_gemm_rs.py compiles a SEPARATE library per mask with -DSPA3D_ABLATION_BUILD -DSPA3D_ABL_RS=mask, never the product: csrc/ablate.inc): compile-time mask, 1 stores wrapped into a 1-MiB window,
 // 2 (AUX) no gelu' arithmetic, 64 (AUX) no aux loads, 4 no LDS-DMA, 8 no MFMAs, 16 no stores and no staging, 32 s_memtime stamps (per-wave sums to RsArgs::dbg), 128 no counted waits / 256 no barriers (WRONG results: timing only)
-#ifndef SPA3D_RS_ABLATE
-#define SPA3D_RS_ABLATE 0
-#endif
-constexpr int RS_ABL = SPA3D_RS_ABLATE;
+constexpr int RS_ABL = SPA3D_ABL_RS;  // csrc/ablate.inc: 0 in libspa3d_hip.so
 __device__ __forceinline__ unsigned long long rs_stamp() {
   unsigned long long t;
   __builtin_amdgcn_sched_barrier(0);

@@ -188,7 +188,10 @@ __global__ __launch_bounds__(256, 1) void gemm_tnb_kernel(TnArgs g) {
         if constexpr (RD) {
           if constexpr (j == 0) { tnb_rd<0>(fn[u ^ 1][i][0], cur[u][1 + i]); tnb_rd<1024>(fn[u ^ 1][i][1], cur[u][1 + i]); }
           else if constexpr (i < 2) rd_wide(TnIC<(j >= 1 ? j - 1 : 0)>{}, i_, cur[u][0]);
-          else if constexpr (j == 7) { rd_wide(TnIC<7>{}, TnIC<0>{}, cur[u][0]); rd_wide(TnIC<7>{}, TnIC<1>{}, cur[u][0]); }
+          else if constexpr (j == 7) {
+            if constexpr (CS && WB) { if (do_cs && w == 3) dot4(cs[1], fw[7][0], fw[7][1]); }   // tile 7's column sums BEFORE its registers are refilled
+            rd_wide(TnIC<7>{}, TnIC<0>{}, cur[u][0]); rd_wide(TnIC<7>{}, TnIC<1>{}, cur[u][0]);
+          }
         }
         if constexpr (MORE && i == 2 && j >= 1 && j <= 5) stage_piece(TnIC<(j >= 1 && j <= 5 ? j - 1 : 0)>{});
         if constexpr (i == 2 && j == 6) {  // the next quarter prefetches from the next slot
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tnb_kernel(TnArgs g) {
         }
       });
       if constexpr (CS) {
-        if constexpr (WB) { if (do_cs && w == (j >> 1)) dot4(cs[j & 1], fw[j][0], fw[j][1]); }        // every wave holds all of B: wave w sums tiles 2w, 2w+1
+        if constexpr (WB) { if constexpr (j < 7 || (TNB_ABL & 4)) { if (do_cs && w == (j >> 1)) dot4(cs[j & 1], fw[j][0], fw[j][1]); } }   // every wave holds all of B: wave w sums tiles 2w, 2w+1 (tile 7: above)
         else if constexpr (j < 3) { if (do_cs) dot4(cs[j], fn[u][j][0], fn[u][j][1]); }                // the wave's own three B tiles, one per MFMA triple
       }
     });

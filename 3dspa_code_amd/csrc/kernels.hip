@@ -283,7 +283,7 @@ void k_layernorm(spa3d_ctx* c, const T* x, const float* scale, T* y, float* stat
   constexpr int NV = VecOf<T>::N;
   const bool al = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
   if (d % NV == 0 && al && d <= 64 * NV * 4) {
-    static int gcap = -1; if (gcap < 0) { const char* e = getenv("SPA3D_LN_GRID"); gcap = e ? atoi(e) : 4096; }
+    constexpr int gcap = 4096;  // measured (tools/bench_ln.py)
     const unsigned g = (unsigned)std::min<int64_t>(cdiv(rows, 8), gcap);
     const int steps = (d / NV + 63) / 64;
     if constexpr (sizeof(T) == 2) {  // the two widths of the step's large LayerNorms: row-partitioned kernels (4.6 -> 5.3 and 3.9 -> 5.2 TB/s)
@@ -387,7 +387,7 @@ void k_layernorm_bwd(spa3d_ctx* c, const T* x, const float* scale, const float* 
   if (c->dry || rows == 0) return;
   ProfScope ps(c, PROF_LN_BWD, 16.0 * (double)rows * d, (double)rows * d * (add ? 4.0 : 3.0) * sizeof(T) + rows * 8.0);  // x, dy, (add), dx
   ps.tag(rows, d, add ? 1 : 0, 0);
-  static int gcapb = -1; if (gcapb < 0) { const char* e = getenv("SPA3D_LNB_GRID"); gcapb = e ? atoi(e) : 1024; }
+  constexpr int gcapb = 1024;
   unsigned g = (unsigned)std::min<int64_t>(cdiv(rows, 4), d <= 512 ? gcapb : 2 * gcapb);  // measured: 1024 blocks at d = 384, 2048 at d = 1280
   constexpr int NV = VecOf<T>::N;
   const bool al = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)add)) & 15) == 0;

@@ -68,14 +68,11 @@ struct MlpFusedArgs {
   int64_t M; int tiles; int nt_store;
   unsigned long long* dbg;  // diagnostic builds with mask 32 only: per-wave cycle sums (s_memtime), else unused
 };
-// diagnostic builds only (tools/ablate_mlp_fused.py compiles a SEPARATE library per mask, never the product): compile-time mask,
+// diagnostic builds only (tools/ablate_mlp_fused.py compiles a SEPARATE library per mask with -DSPA3D_ABLATION_BUILD -DSPA3D_ABL_MF=mask, never the product: csrc/ablate.inc): compile-time mask,
 // 1 h / hpre stores wrapped into a 1-MiB window (no HBM write stream), 2 no gelu arithmetic, 4 no LDS-DMA, 8 no MFMAs, 16 no y stores,
 // 32 s_memtime stamps at the phase seams (per-wave sums to MlpFusedArgs::dbg; shares, not run time), 64 plain instead of non-temporal stores,
 // 128 no counted wait at the phase ends (WRONG results: timing only), 256 no phase barriers (WRONG results: timing only)
-#ifndef SPA3D_MF_ABLATE
-#define SPA3D_MF_ABLATE 0
-#endif
-constexpr int MF_ABL = SPA3D_MF_ABLATE;
+constexpr int MF_ABL = SPA3D_ABL_MF;  // csrc/ablate.inc: 0 in libspa3d_hip.so
 #ifndef SPA3D_MF_FDEPTH
 #define SPA3D_MF_FDEPTH 1
 #endif
@@ -406,6 +403,9 @@ bool mlp_fused_fwd(spa3d_ctx* c, const bf16_t* na, const bf16_t* a, bf16_t* y, b
                    const bf16_t* wpk, const float* b_in, const float* b_out) {
   if (d != MF_D || mlp != MF_H || M < 1 || !wpk || !b_in || !b_out) return false;
   if (c->dry) return true;
+  // 16-byte vector loads / stores and LDS-DMA on every operand: a misaligned pointer from a C-ABI caller is refused, not faulted on (gemm_rs / gemm_nt_bf16 do the same)
+  for (const void* p : {(const void*)na, (const void*)a, (const void*)y, (const void*)h, (const void*)hpre, (const void*)wpk})
+    if (((uintptr_t)p) & 15) return false;
   MlpFusedArgs g{};
   g.na = na; g.a = a; g.y = y; g.h = h; g.hpre = hpre; g.wpk = (const char*)wpk; g.b_in = b_in; g.b_out = b_out; g.M = M;
   g.tiles = (int)((M + 127) / 128);

@@ -500,8 +500,8 @@ template <typename T> struct Net {
       // ONCE, straight into the compact (pruned) order; dropped frame tokens are neither computed nor gathered, readout rows come from k_embed_maps
       if (emb_wt && c->gemm_impl != 1 && (g.dino_feature_dim > 0) == (k.dino != nullptr) && (g.depth_feature_dim > 0) == (k.depthf != nullptr) &&
           nseq * (int64_t)T_ < 0x7fffffffLL && rows < 0x7fffffffLL) {
+        const int64_t mk_emb = c->ar.mark();
         T* out = alloc<T>(rows_g * d);
-        const int64_t mk_maps = c->ar.mark();
         int32_t* arow = alloc<int32_t>(rows); int32_t* crow = alloc<int32_t>(rows);
         k_embed_maps<T>(c, rg.off ? k.row_src : nullptr, rows, S, T_, arow, crow, out, readout, d);
         GemmDesc e{};
@@ -510,8 +510,8 @@ template <typename T> struct Net {
         if (k.dino) { e.A2 = k.dino; e.sA2m = g.dino_feature_dim; e.K1 = tok.K; }
         if (k.depthf) { e.r1_x = k.depthf; e.r1_w = depth.src[0]; }
         emb_done = gemm_nt_bf16(c, e);
-        (void)mk_maps;  // (the maps stay allocated for the chunk: the launch is asynchronous)
-        if (emb_done) { k.tok0 = out; }
+        if (emb_done) k.tok0 = out;   // (the maps stay allocated for the chunk: the launch is asynchronous)
+        else c->ar.release(mk_emb);   // refused: the multi-pass path below allocates its own buffers; k_embed_maps wrote only into what is released here
       }
     }
     T* tokc = (rg.off && !emb_done) ? alloc<T>(rows_g * d) : nullptr;
@@ -650,10 +650,18 @@ template <typename T> struct Net {
   // Overlap of the data-parallel gradient all-reduce with the backward: parameter gradients accumulate over the sample chunks, so
   // a leaf is final only in the LAST chunk's backward -- in reverse graph order.  The caller may register two events (spa3d_set_grad_events);
   // each is recorded on the launch stream when its segment of the flat gradient buffer (spa3d_grad_segments) has received its last
-  // contribution; the third segment (embedding, track encoder, state_init leaves) is final when the call's work is.  Not with a loss scale
-  // (fp16: the whole buffer is rescaled at the end).
+  // contribution; the third segment (embedding, track encoder, state_init leaves) is final when the call's work is.  With a loss scale (fp16) a
+  // finished segment is unscaled right before its event; the rest of the buffer at the end of the call.
+  int64_t seg_lo[2] = {0, 0}, seg_hi[2] = {0, 0};  // flat ranges of segment 0 ([b2, n): readout side) and 1 ([b1, b2): latent stacks), spa3d_grad_segments
+  const float* scale_dev = nullptr;                  // fp16 mode: the call's loss scale (device)
+  bool seg_unscaled[2] = {false, false};
   void grad_segment_done(int i) {
-    if (c->dry || !c->last_chunk || !c->grad_ev[i] || c->loss_scale != 1.f) return;
+    if (c->dry || !c->last_chunk || !c->grad_ev[i]) return;
+    if (c->loss_scale != 1.f) {  // fp16: bring the finished segment back to true scale NOW (a power of two: exact) so that its all-reduce can start behind the event
+      if (!scale_dev || seg_hi[i] <= seg_lo[i]) return;
+      k_unscale(c, G + seg_lo[i], scale_dev, seg_hi[i] - seg_lo[i]);
+      seg_unscaled[i] = true;
+    }
     if (hipEventRecord((hipEvent_t)c->grad_ev[i], c->stream) != hipSuccess && !c->hip_err) { c->hip_err = -6; c->err = "recording a gradient-segment event failed"; }
     else c->grad_ev_gen[i] += 1;
   }
@@ -781,10 +789,18 @@ void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
     if (c->loss_scale != 1.f) k_set_loss_scale(c, denom_dev, L1_WEIGHT, c->loss_scale, denom_dev + 1);  // sums[7]
     if (!a.accumulate) k_zero(c, a.G, c->nparams * 4);
   }
-  for (int64_t b0 = 0; b0 < b->B; b0 += Bc) {
+  if (train && c->loss_scale != 1.f) {
+    int64_t b4[4];
+    if (spa3d_grad_segments(c, b4) == SPA3D_OK) { net.seg_lo[0] = b4[2]; net.seg_hi[0] = b4[3]; net.seg_lo[1] = b4[1]; net.seg_hi[1] = b4[2]; }
+    net.scale_dev = denom_dev + 1;
+  }
+  // The ragged chunk (B % Bc samples) runs FIRST, so the last chunk -- the one under whose track-encoder backward the gradient segments are all-reduced -- is a
+  // full one (B = 64, Bc = 9: 9 samples of encoder backward to hide behind instead of 1)
+  for (int64_t b0 = 0, cur = 0; b0 < b->B; b0 += cur) {
     typename Net<T>::Chunk k{};
-    c->last_chunk = b0 + Bc >= b->B;
-    k.Bc = std::min<int64_t>(Bc, b->B - b0); k.N = b->N; k.Q = b->Q; k.T_ = b->T; k.S = b->T + (g.model_kind == 1 ? 0 : 1); k.nseq = k.Bc * b->N;
+    cur = (b0 == 0 && b->B % Bc) ? b->B % Bc : std::min<int64_t>(Bc, b->B - b0);
+    c->last_chunk = b0 + cur >= b->B;
+    k.Bc = cur; k.N = b->N; k.Q = b->Q; k.T_ = b->T; k.S = b->T + (g.model_kind == 1 ? 0 : 1); k.nseq = k.Bc * b->N;
     const int64_t mk = c->ar.mark();
     if (c->poison && !c->dry) {  // test mode: everything this chunk may allocate starts as NaN (0xFFFF / 0xFFFFFFFF) instead of the previous chunk's values
       const int64_t o = (mk + 255) & ~int64_t(255);
@@ -812,7 +828,15 @@ void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
     }
     c->ar.release(mk);
   }
-  if (train && c->loss_scale != 1.f) k_unscale(c, a.G, denom_dev + 1, c->nparams);  // fp32 gradient buffer back to true scale (exact: power of two)
+  if (train && c->loss_scale != 1.f) {  // fp32 gradient buffer back to true scale (exact: power of two); segments already unscaled at their events are skipped
+    const int64_t lo1 = net.seg_lo[1], lo0 = net.seg_lo[0];
+    if (!net.seg_unscaled[0] && !net.seg_unscaled[1]) k_unscale(c, a.G, denom_dev + 1, c->nparams);
+    else {
+      k_unscale(c, a.G, denom_dev + 1, lo1);
+      if (!net.seg_unscaled[1]) k_unscale(c, a.G + lo1, denom_dev + 1, lo0 - lo1);
+      if (!net.seg_unscaled[0]) k_unscale(c, a.G + lo0, denom_dev + 1, c->nparams - lo0);
+    }
+  }
   if (train && a.loss3) k_loss_finalize(c, sums, poison, denom_dev, L1_WEIGHT, BCE_WEIGHT, a.loss3);
 }
 

@@ -150,10 +150,12 @@ int spa3d_op_mlp_fused(const void* na, const void* a, const void* w_in, const fl
                        void* h, void* hpre, int64_t M, int32_t d, int32_t mlp, int32_t dtype, void* ws, int64_t ws_bytes, void* stream) {
   FWD16(spa3d_op_mlp_fused_f16(na, a, w_in, b_in, w_out, b_out, y, h, hpre, M, d, mlp, dtype, ws, ws_bytes, stream))
   if (!na || !a || !w_in || !b_in || !w_out || !b_out || !y || !h || !hpre || dtype == SPA3D_F32) return SPA3D_ERR_ARG;
+  if (d != 384 || mlp != 1536 || M < 1) return SPA3D_ERR_ARG;   // shape first: a wrong shape is an argument error whatever the workspace
+  for (const void* p : {na, a, (const void*)y, (const void*)h, (const void*)hpre, w_in, w_out})
+    if (((uintptr_t)p) & 15) return SPA3D_ERR_ARG;               // 16-byte vector / LDS-DMA accesses on every operand
   OpCtx c(stream, ws, ws_bytes);
   bf16_t* wpk = c.alloc<bf16_t>(mlp_fused_pack_elems());
   if (c.ar.overflow) return SPA3D_ERR_WORKSPACE;
-  if (d != 384 || mlp != 1536) return SPA3D_ERR_ARG;
   mlp_fused_pack<bf16_t>(&c, (const bf16_t*)w_in, (const bf16_t*)w_out, wpk);
   if (!mlp_fused_fwd(&c, (const bf16_t*)na, (const bf16_t*)a, (bf16_t*)y, (bf16_t*)h, (bf16_t*)hpre, M, d, mlp, wpk, b_in, b_out)) return SPA3D_ERR_ARG;
   return c.status();

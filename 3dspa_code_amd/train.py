@@ -155,12 +155,13 @@ class TrainState:
     self._noise_fn = noise_fn or _hip_uniform_noise
     self._evaluate = evaluate or self._hip_evaluate
     self._noise_cache = {}
-    # gradient all-reduce under the backward: needs the HIP compute (it records the segment events), a GPU, no loss scale
+    # gradient all-reduce under the backward: needs the HIP compute (it records the segment events) and a GPU; fp16 too -- the library
+    # unscales a finished segment (a power of two: exact) right before it records the segment's event
     self._overlap = None
     import os
     if os.environ.get('SPA3D_DP_OVERLAP', '1') == '0':  # A/B switch for scaling runs
       overlap_allreduce = False
-    if overlap_allreduce and compute is None and on and flat.is_cuda and model.precision != 'fp16' and (self.world > 1 or self.force):
+    if overlap_allreduce and compute is None and on and flat.is_cuda and (self.world > 1 or self.force):
       lib = _lib.load()
       h = model._handle(*model._dims_from_params(self.params))[0]
       b4 = (C.c_int64 * 4)()

@@ -180,13 +180,32 @@ def roofline_from_profile(spa3d, model, handle, steps, peak_flops, pmc=True):
   return out, mfma_flops
 
 
-def cpu_threads():
-  # the box's CPU share, not the host's core count: os.cpu_count() over-subscribes a cgroup-limited container
+def _cgroup_cpu_quota():
+  """CPUs this process may use by its cgroup's CPU bandwidth limit (v2 cpu.max, else v1 cfs quota / period); None = unlimited or unreadable."""
   try:
-    cores = len(os.sched_getaffinity(0))
+    q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+    return None if q == 'max' else float(q) / float(per)
+  except (OSError, ValueError):
+    pass
+  try:
+    q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read()); per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+    return None if q <= 0 else q / per
+  except (OSError, ValueError):
+    return None
+
+
+def cpu_threads():
+  """Threads for the CPU baseline = the host cores this process really has: min(scheduler affinity, cgroup CPU quota) -- os.cpu_count() over-subscribes a
+  cgroup-limited container, a fixed cap under-states a large host.  Returns (threads, affinity, quota)."""
+  try:
+    aff = len(os.sched_getaffinity(0))
   except AttributeError:
-    cores = os.cpu_count() or 1
-  return max(1, min(cores, int(os.environ.get('SPA3D_CPU_THREADS', 16))))
+    aff = os.cpu_count() or 1
+  quota = _cgroup_cpu_quota()
+  n = aff if quota is None else min(aff, max(1, int(quota)))
+  if os.environ.get('SPA3D_CPU_THREADS'):
+    n = min(n, int(os.environ['SPA3D_CPU_THREADS']))
+  return max(1, n), aff, quota
 
 
 def cpu_baseline():
@@ -194,7 +213,8 @@ def cpu_baseline():
   (B=2, 64+16 tracks, T=24, xyz-only, fp32), FULL step = fwd + loss + bwd + clip + AdamW, median of 5 after 1 warm-up
   (SURVEY 8(d)).  The reference's own JAX path cannot run here."""
   from oracle import spa3d_oracle as O
-  torch.set_num_threads(cpu_threads())
+  nthr, aff, quota = cpu_threads()
+  torch.set_num_threads(nthr)
   cfg = O.Config(num_output_frames=24, use_dino=False, use_depth=False)
   p = O.tree_flatten(O.init_params(cfg, seed=0, with_dino=False, with_depth=False))
   m_ = {k: torch.zeros_like(v) for k, v in p.items()}
@@ -209,7 +229,7 @@ def cpu_baseline():
     O.adamw_step(p, g, m_, v_, step, 1e-4)
     ts.append(time.perf_counter() - t0)
   t = statistics.median(ts[1:])
-  return {'value': 160.0 / t, 'unit': 'tracks/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+  return {'value': 160.0 / t, 'unit': 'tracks/s', 'cores': torch.get_num_threads(), 'kind': 'port', 'cpu_affinity': aff, 'cgroup_cpu_quota': quota,
           'sample': f'cfg#1 B=2, 64 support+16 query, T=24, xyz-only fp32, full step fwd+loss+bwd+clip+AdamW (median of 5 after 1 warm-up): '
                     f'{t:.2f} s/step, {1.02e12 / t / 1e9:.1f} GFLOP/s of F_ref=1.02 TFLOP'}
 

@@ -21,8 +21,9 @@
  * allocation inside (the caller supplies one workspace from its own allocator); every call
  * is asynchronous on the hipStream_t passed as `void* stream` -- except that, in the 16-bit
  * modes, two 4-byte plan counts per sample chunk (kept frame tokens; distinct query frames) are
- * read back to the host, which synchronises the stream at those points (SPA3D_PRUNE=0 /
- * SPA3D_RO_SHARE=0 in the environment remove the reads together with the savings they size);
+ * read back to the host, which synchronises the stream at those points (spa3d_set_option(h, "prune", 0) and
+ * spa3d_set_option(h, "ro_share", 0) remove the reads together with the savings they size; no compute path reads the environment --
+ * the six options may only be PRESET from it when spa3d_create runs);
  * one handle per stream (thread-compatible, not thread-safe).  All tensors are row-major contiguous in the
  * reference's layouts.  Parameters and gradients are ONE flat float32 buffer each whose
  * leaf order / offsets the library defines (spa3d_leaf_*); names are the Flax paths of
@@ -158,7 +159,8 @@ int spa3d_adamw_step(float* params, const float* grads, float* m, float* v, int6
  *   "chunk"           samples processed at a time; 0 = as many as fit the workspace
  *   "gemm_impl"       0 product dispatch | 1 generic strided MFMA kernel only | 2 tiled kernels | diagnostics that put small problems on the big
  *                     kernels: 3 every eligible GEMM on the 8-phase kernels, 4 the same with the non-persistent 128x384 kernel, 5 without the
- *                     single-buffer short-K kernel, 6 tiled GEMMs without the round-4 kernels (MLP forward as two GEMMs, multi-pass input embedding, no row-stationary K = 384 kernel).  (The `impl` argument of spa3d_op_linear* takes
+ *                     single-buffer short-K kernel, 6 tiled GEMMs without the round-4 / round-5 kernels (MLP forward as two GEMMs, multi-pass input embedding, no row-stationary K = 384 kernel,
+ *                     no large-register-tile dW kernel), 8 the product dispatch without the round-5 large-register-tile dW kernel, 9 = 3 with every divisible dW on that kernel.  (The `impl` argument of spa3d_op_linear* takes
  *                     the same values; spa3d_op_linear: | 16 = also write the pre-activation, the MLP-in form of the step.)
  *   "attn_impl"       0 product dispatch | 1 generic composition | 2 fused kernels | 3, 4 fused with the split-pass backward on 4 / 8 waves (tests)
  * and one test mode: "poison" 0/1 -- the workspace is filled with 16-bit NaN patterns before every sample chunk, so a read of a row that this

@@ -100,3 +100,22 @@ def test_mlp_fused_rejects_other_widths(lib):
   rc = lib.spa3d_op_mlp_fused(x.data_ptr(), x.data_ptr(), x.data_ptr(), f.data_ptr(), x.data_ptr(), f.data_ptr(), x.data_ptr(), x.data_ptr(),
                               x.data_ptr(), 128, 512, 2048, BF16, ws.data_ptr(), ws.numel(), _s())
   assert rc == 1
+
+
+def test_mlp_fused_refuses_misaligned_pointers_and_reports_shape_before_workspace(lib):
+  """every operand is accessed with 16-byte vector loads / stores or LDS-DMA -- a misaligned pointer from a C-ABI caller must come back as
+  SPA3D_ERR_ARG (1), not fault on the GPU; and a wrong shape is an argument error even when the workspace is too small to say so first."""
+  M = 256
+  buf = torch.zeros(M * 1536 + 64, device='cuda', dtype=torch.bfloat16)
+  w = torch.zeros(384 * 1536, device='cuda', dtype=torch.bfloat16)
+  f = torch.zeros(2048, device='cuda')
+  ws = torch.empty(32 << 20, dtype=torch.uint8, device='cuda')
+  good = [buf.data_ptr(), buf.data_ptr(), w.data_ptr(), f.data_ptr(), w.data_ptr(), f.data_ptr(), buf.data_ptr(), buf.data_ptr(), buf.data_ptr()]
+  assert lib.spa3d_op_mlp_fused(*good, M, 384, 1536, BF16, ws.data_ptr(), ws.numel(), _s()) == 0
+  for i in (0, 1, 2, 4, 6, 7, 8):  # na, a, w_in, w_out, y, h, hpre
+    bad = list(good); bad[i] += 2
+    assert lib.spa3d_op_mlp_fused(*bad, M, 384, 1536, BF16, ws.data_ptr(), ws.numel(), _s()) == 1, i
+  tiny = torch.empty(1024, dtype=torch.uint8, device='cuda')
+  assert lib.spa3d_op_mlp_fused(*good, M, 512, 2048, BF16, tiny.data_ptr(), tiny.numel(), _s()) == 1   # shape error, not ERR_WORKSPACE
+  assert lib.spa3d_op_mlp_fused(*good, M, 384, 1536, BF16, tiny.data_ptr(), tiny.numel(), _s()) == 2   # right shape, workspace too small
+  torch.cuda.synchronize()

@@ -237,6 +237,25 @@ def test_adamw_step_matches_oracle(lib):
   assert max_abs(pd, P['a']) < 1e-6 and max_abs(md, M['a']) < 1e-7 and max_abs(vd, V['a']) < 1e-9
 
 
+@pytest.mark.parametrize('step,skipped', [(7, 3), (5, 5), (2, 9)])
+def test_adamw_step_bias_correction_counts_applied_updates(lib, step, skipped):
+  """scratch[3] = updates skipped so far (non-finite gradient norm).  The Adam bias correction then runs at step + 1 - skipped -- the number of
+  updates actually applied to m and v -- clamped at 1 (include/spa3d.h, spa3d_adamw_step): the update must equal the oracle's (optax chain, train.py:239-242) at
+  step - skipped, and at step 0 when the counter has run past the step count (a resumed scratch that disagrees with `step`: the clamp, not a division by zero)."""
+  g = torch.Generator().manual_seed(6)
+  n = 50021
+  p = torch.randn(n, generator=g); gr = torch.randn(n, generator=g) * 0.01
+  m = torch.randn(n, generator=g) * 0.001; v = torch.rand(n, generator=g) * 1e-4
+  pd, gd, md, vd = p.cuda(), gr.cuda(), m.cuda(), v.cuda()
+  scratch = torch.zeros(1024, device='cuda'); scratch[3] = float(skipped)
+  assert lib.spa3d_adamw_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, 3e-4, step, 1.0, 0.9, 0.999, 1e-8, 0.01,
+                              scratch.data_ptr(), _s()) == 0
+  P, G, M, V = {'a': p.double().clone()}, {'a': gr.double()}, {'a': m.double().clone()}, {'a': v.double().clone()}
+  O.adamw_step(P, G, M, V, step=max(step - skipped, 0), lr=3e-4)
+  assert float(scratch[2]) == 0.0 and float(scratch[3]) == float(skipped)   # a finite step is applied and does not touch the counter
+  assert max_abs(pd, P['a']) < 1e-6 and max_abs(md, M['a']) < 1e-7 and max_abs(vd, V['a']) < 1e-9
+
+
 # ------------------------------------------------------------------------------------------------ tiled bf16 kernels (impl=2)
 @pytest.mark.parametrize('M,N,K,act,res,bias', [(1000, 384, 256, 0, False, True), (4133, 2304, 384, 0, False, False),
                                                 (777, 1536, 384, 1, False, True), (2050, 384, 1536, 0, True, True),

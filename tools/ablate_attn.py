@@ -15,7 +15,7 @@ if not os.environ.get('ABL1_CHILD'):
   objs = [os.path.join(b.HERE, 'build', o) for o in sorted(os.listdir(os.path.join(b.HERE, 'build'))) if o.endswith('.o') and o != 'attention_fused.o']
   if not MODE4:
     ao = os.path.join(out, 'attention_fused_ablate.o')
-    subprocess.check_call([b._hipcc()] + b.FLAGS + ['-DSPA3D_ABLATE', '-c', os.path.join(b.CSRC, 'attention_fused.hip'), '-o', ao])
+    subprocess.check_call([b._hipcc()] + b.FLAGS + ['-DSPA3D_ABLATION_BUILD', '-DSPA3D_ABL_ATTN=1', '-c', os.path.join(b.CSRC, 'attention_fused.hip'), '-o', ao])
     subprocess.check_call([b._hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib_path] + objs + [ao])
 if MODE4 and not os.environ.get('ABL1_CHILD'):
   from concurrent.futures import ThreadPoolExecutor

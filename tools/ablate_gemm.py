@@ -11,7 +11,7 @@ out = os.path.join(ROOT, 'tools', '_ablate'); os.makedirs(out, exist_ok=True)
 b.build(verbose=False)
 objs = [os.path.join(b.HERE, 'build', o) for o in sorted(os.listdir(os.path.join(b.HERE, 'build'))) if o.endswith('.o') and o != 'gemm_fast.o']
 ao = os.path.join(out, 'gemm_fast_ablate.o')
-subprocess.check_call([b._hipcc()] + b.FLAGS + ['-DSPA3D_ABLATE', '-c', os.path.join(b.CSRC, 'gemm_fast.hip'), '-o', ao])
+subprocess.check_call([b._hipcc()] + b.FLAGS + ['-DSPA3D_ABLATION_BUILD', '-DSPA3D_ABL_NT=1', '-c', os.path.join(b.CSRC, 'gemm_fast.hip'), '-o', ao])
 lib_path = os.path.join(out, 'libspa3d_ablate_gemm.so')
 subprocess.check_call([b._hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib_path] + objs + [ao])
 import torch, spa3d

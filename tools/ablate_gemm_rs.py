@@ -16,7 +16,7 @@ import torch
 libs = {}
 for m in masks:
   ao = os.path.join(out, f'gemm_rs_abl{m}.o')
-  subprocess.check_call([b._hipcc()] + b.FLAGS + [f'-DSPA3D_RS_ABLATE={m}'] + extra + ['-c', os.path.join(b.CSRC, 'gemm_rs.hip'), '-o', ao])
+  subprocess.check_call([b._hipcc()] + b.FLAGS + ['-DSPA3D_ABLATION_BUILD', f'-DSPA3D_ABL_RS={m}'] + extra + ['-c', os.path.join(b.CSRC, 'gemm_rs.hip'), '-o', ao])
   lp = os.path.join(out, f'libspa3d_rs_abl{m}.so')
   subprocess.check_call([b._hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lp] + objs + [ao])
   libs[m] = C.CDLL(lp)

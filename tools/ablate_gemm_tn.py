@@ -13,7 +13,7 @@ import torch
 libs = {}
 for m in (0, 1, 2, 3):
   ao = os.path.join(out, f'gemm_fast_tnabl{m}.o')
-  subprocess.check_call([b._hipcc()] + b.FLAGS + [f'-DSPA3D_TN_ABL={m}', '-c', os.path.join(b.CSRC, 'gemm_fast.hip'), '-o', ao])
+  subprocess.check_call([b._hipcc()] + b.FLAGS + ['-DSPA3D_ABLATION_BUILD', f'-DSPA3D_ABL_TN={m}', '-c', os.path.join(b.CSRC, 'gemm_fast.hip'), '-o', ao])
   lp = os.path.join(out, f'libspa3d_tnabl{m}.so')
   subprocess.check_call([b._hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lp] + objs + [ao])
   libs[m] = C.CDLL(lp)
