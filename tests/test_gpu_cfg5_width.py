@@ -78,7 +78,7 @@ def test_cfg5_width_fp16_vs_fp32_parity_mode_n4096():
   _plan(lo[4])
   ref = _run(spa3d, 'fp32', batch, noise, poison=0)
   _compare('cfg#5 width (N = 4096, Q = 2048, T = 300): fp16 default dispatch vs the fp32 parity mode', lo, ref,
-           (3.0e-3, 3.0e-3, 1.5e-4, 6.0e-2, 2.0e-5), ('first run of this test', '', '', '', ''))
+           (1.55e-3, 1.55e-3, 3.0e-5, 4.4e-2, 5.6e-6), ('1.03e-3 (round 5)', '1.03e-3', '2.0e-5', '2.9e-2: tracks_to_latents/layer_0/cross_att/dense_query/kernel', '3.7e-6'))
 
 
 def test_cfg5_full_width_fp16_vs_bf16_n8192():
@@ -92,4 +92,4 @@ def test_cfg5_full_width_fp16_vs_bf16_n8192():
   # bf16 reads bf16-rounded feature planes: part of the difference below is that input rounding (2^-9 relative), as in every bf16-vs-fp16 comparison of the suite
   ref = _run(spa3d, 'bf16', batch, noise)
   _compare('cfg#5 FULL width (N = 8192, Q = 2048, T = 300): fp16 vs bf16, default dispatch both', lo, ref,
-           (2.0e-2, 2.0e-2, 5e-4, 0.35, 1.5e-3), ('first run of this test', '', '', '', ''))
+           (1.3e-2, 1.3e-2, 1.4e-4, 0.11, 1.0e-4), ('8.5e-3 (round 5)', '8.5e-3', '9.3e-5', '7.3e-2: decompress_attn/layer_2/self_att/dense_key/kernel', '6.6e-5'))

@@ -68,7 +68,7 @@ class Gates:
 
   def check(self):
     print(f'  gates: {self.title}')
-    print(f'    {"quantity":44s} {"this run":>11s} {"bound":>11s}   measured in round 4')
+    print(f'    {"quantity":44s} {"this run":>11s} {"bound":>11s}   measured when the bound was set')
     for n, v, b, m, ok in self.rows:
       print(f'    {n:44s} {v:11.4e} {b:11.4e}   {m}{"" if ok else "   <-- FAILED"}')
     bad = [r[0] for r in self.rows if not r[4]]
