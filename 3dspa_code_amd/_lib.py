@@ -79,6 +79,8 @@ _SIGS = {
                                      C.c_void_p]),
     'spa3d_op_layernorm_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    'spa3d_op_qkv_attention': (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 3
+                               + [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     'spa3d_op_attention': (C.c_int, [C.c_void_p] * 3 + [C.c_int64] * 3 + [C.c_void_p] * 3 + [C.c_int64] + [C.c_int32] * 4
                            + [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     'spa3d_op_attention_bwd': (C.c_int, [C.c_void_p] * 3 + [C.c_int64] * 3 + [C.c_void_p] * 3 + [C.c_int64]

@@ -9,8 +9,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libspa3d_hip.so')
-SOURCES = ['kernels.hip', 'gemm_generic.hip', 'gemm_fast.hip', 'gemm_tnb.hip', 'gemm_rs.hip', 'mlp_fused.hip', 'attention.hip', 'attention_fused.hip', 'ops.hip', 'samplers.hip', 'model.hip']
-F16_SOURCES = ['kernels.hip', 'gemm_generic.hip', 'gemm_fast.hip', 'gemm_tnb.hip', 'gemm_rs.hip', 'mlp_fused.hip', 'attention.hip', 'attention_fused.hip', 'ops.hip', 'model.hip']
+SOURCES = ['kernels.hip', 'gemm_generic.hip', 'gemm_fast.hip', 'gemm_tnb.hip', 'gemm_rs.hip', 'mlp_fused.hip', 'attention.hip', 'attention_fused.hip', 'qkv_attn.hip', 'ops.hip', 'samplers.hip', 'model.hip']
+F16_SOURCES = ['kernels.hip', 'gemm_generic.hip', 'gemm_fast.hip', 'gemm_tnb.hip', 'gemm_rs.hip', 'mlp_fused.hip', 'attention.hip', 'attention_fused.hip', 'qkv_attn.hip', 'ops.hip', 'model.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function', '-Wno-inline-asm',
          '-Wno-unused-variable', '-Wno-unused-but-set-variable']
 
@@ -31,7 +31,7 @@ def _stale(out, deps):
 
 def build(force: bool = False, verbose: bool = True) -> str:
   hipcc = _hipcc()
-  hdrs = [os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'tn_args.hpp'), os.path.join(CSRC, 'ablate.inc'), os.path.join(HERE, '..', 'include', 'spa3d.h')]
+  hdrs = [os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'tn_args.hpp'), os.path.join(CSRC, 'ablate.inc'), os.path.join(CSRC, 'attn_common.hpp'), os.path.join(HERE, '..', 'include', 'spa3d.h')]
   objdir = os.path.join(HERE, 'build')
   os.makedirs(objdir, exist_ok=True)
   srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]

@@ -168,6 +168,8 @@ struct spa3d_ctx {
   int embed_fused = 1;    // input embedding as ONE GEMM over the concatenated K written once, in compact row order (model.hip encode_chunk); gemm_impl 6 = the multi-pass path
   int mlp_fused = 1;      // track-encoder MLP forward as ONE sequence-resident kernel (mlp_fused.hip); gemm_impl 6 = the two tiled GEMMs
   int rs_gemm = 1;        // K = 384 projections on the row-stationary kernel (gemm_rs.hip); gemm_impl 6 = the tiled kernels; 7 (ops) = required
+  int qkv_attn = 0;       // track-encoder QKV projection + attention forward as ONE kernel (qkv_attn.hip): built and measured in round 5, 1.47x SLOWER than the
+                          // projection GEMM + attention kernel pair (profiles/r05_qkv_attn_fused.log), so opt-in only: attn_impl 6
   int poison = 0;         // spa3d_set_option "poison": NaN-fill the workspace before every chunk and every op output before its launch (tests)
   bool tn_colsum_fused = false;  // set by gemm_tn_bf16: the last call also produced GemmDesc::colsum_out
   Prof prof;
@@ -188,10 +190,11 @@ inline void apply_gemm_impl(spa3d_ctx* c, int v) {
   if (v == 8) c->tn_big = 0;
 }
 // attn_impl: 0 product dispatch | 1 generic composition (GEMMs + softmax kernels) | 2 fused kernels (ops: error when unusable) | 3 / 4 fused with the
-// split-pass backward on 4 / 8 waves also where the four-image kernel would run (S <= 160; tests)
+// split-pass backward on 4 / 8 waves also where the four-image kernel would run (S <= 160; tests) | 6 fused kernels with the track encoder's QKV projection + attention forward as ONE launch (qkv_attn.hip)
 inline void apply_attn_impl(spa3d_ctx* c, int v) {
   c->attn_impl = v == 1 ? 1 : (v >= 2 ? 2 : 0);
   c->attn_bwd_mode = v == 3 ? 2 : (v == 4 ? 3 : 0);
+  c->qkv_attn = v == 6;   // 6 = the fused kernels with the round-5 QKV projection + attention forward (opt-in: measured slower)
 }
 
 struct ProfScope {  // records an event pair around the launches issued in its lifetime
@@ -264,6 +267,11 @@ template <typename S> void gemm_rs_pack(spa3d_ctx* c, const S* w, int64_t sk, in
 // gelu_pre != null: C = (A . W + bias) o gelu'(gelu_pre) (gelu_pre in C's layout, row stride ldpre): the MLP backward's dh
 bool gemm_rs(spa3d_ctx* c, const bf16_t* A, int64_t lda, const bf16_t* wpk, const float* bias, bf16_t* C, int64_t ldc, int64_t M, int N,
              const bf16_t* gelu_pre = nullptr, int64_t ldpre = 0);
+// QKV projection + attention forward of one (sequence, head) per workgroup pass (qkv_attn.hip): d = 384, Dh = 96, S <= 160; false = shape not covered
+int64_t qkv_attn_pack_elems(int H);
+template <typename S> void qkv_attn_pack(spa3d_ctx* c, const S* wq, const S* wk, const S* wv /* [384][E] */, int E, int H, bf16_t* wpk);
+bool qkv_attn_fwd(spa3d_ctx* c, const bf16_t* nq, int64_t ldn, const bf16_t* wpk, const float* sq, const float* sk, const float* km, int64_t nseq, int S, int H,
+                  int Dh, int d, bf16_t* qkv, bf16_t* o, float* lse, const int32_t* seq_off, int64_t total_rows);
 // sequence-resident MLP forward for d = 384, mlp = 1536 (mlp_fused.hip): y = a + MLP(na), h / hpre kept; false = shape not covered
 template <typename S> void mlp_fused_pack(spa3d_ctx* c, const S* w_in /*[384][1536]*/, const S* w_out /*[1536][384]*/, bf16_t* wpk);
 int64_t mlp_fused_pack_elems();

@@ -54,6 +54,7 @@ template <typename T> struct BlockW {
   float *g_norm_q, *g_norm_attn, *g_sq, *g_sk, *g_csq = nullptr, *g_csk = nullptr;
   Lin<T> qkv, out, cq, ckv, cout, mlp_in, mlp_out;
   T* mlp_pk = nullptr;  // both MLP kernels as the fused forward kernel's weight stream (mlp_fused.hip; d = 384, mlp = 1536, 16-bit modes)
+  T* qkv_pk = nullptr;  // the q | k | v kernels as the per-head fragment stream of the fused projection + attention forward (qkv_attn.hip; d = 384, 96-wide heads)
 };
 template <typename T> struct XfW { std::vector<BlockW<T>> blocks; const float* norm_enc; float* g_norm_enc; int d; };
 template <typename T> struct BlockStash {
@@ -152,6 +153,10 @@ template <typename T> struct Net {
         if (c->mlp_fused && !w.cross && d == 384 && mlp == 1536) {
           w.mlp_pk = alloc<T>(mlp_fused_pack_elems());
           mlp_fused_pack<float>(c, w.mlp_in.src[0], w.mlp_out.src[0], w.mlp_pk);
+        }
+        if (c->qkv_attn && c->gemm_impl != 1 && c->attn_impl != 1 && !w.cross && d == 384 && Dh == 96) {
+          w.qkv_pk = alloc<T>(qkv_attn_pack_elems(H));
+          qkv_attn_pack<float>(c, w.qkv.src[0], w.qkv.src[1], w.qkv.src[2], E, H, w.qkv_pk);
         }
       }
       x.blocks.push_back(w);
@@ -284,10 +289,17 @@ template <typename T> struct Net {
       nq = alloc<T>(Mg * d); st1 = alloc<float>(M * 2);
       k_layernorm<T>(c, x, w.norm_q, nq, st1, M, d);                                    // :76-78
       qkv = alloc<T>(Mg * 3 * E);
-      lin_fwd(w.qkv, nq, qkv, Mg);                                                       // :154-173
     }
     T* o = alloc<T>(Mg * E); float* lse = alloc<float>(M * H * 2);
-    attn_fwd(qkv, qkv + E, qkv + 2 * E, 3 * E, 3 * E, 3 * E, w.sq, w.sk, km, nseq, S, S, o, lse, rg);  // :166-175
+    bool qa = false;
+    if constexpr (sizeof(T) == 2) {  // :154-175 as ONE kernel per (sequence, head): q | k | v are written once and never read back by the forward
+      if (!sh && w.qkv_pk && S <= 160)   // (opt-in: attn_impl 6)
+        qa = qkv_attn_fwd(c, nq, d, w.qkv_pk, w.sq, w.sk, km, nseq, S, H, Dh, d, qkv, o, lse, rg.off, rg.off ? rg.rows : 0);
+    }
+    if (!qa) {
+      if (!sh) lin_fwd(w.qkv, nq, qkv, Mg);                                              // :154-173
+      attn_fwd(qkv, qkv + E, qkv + 2 * E, 3 * E, 3 * E, 3 * E, w.sq, w.sk, km, nseq, S, S, o, lse, rg);  // :166-175
+    }
     T* a = alloc<T>(Mg * d);
     lin_fwd(w.out, o, a, Mg, EPI_NONE, x);                                              // :178-183 + residual :79,90
     T *cq = nullptr, *ckv = nullptr, *co = nullptr; float* clse = nullptr;

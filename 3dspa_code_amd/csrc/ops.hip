@@ -92,6 +92,9 @@ int spa3d_op_linear_bwd_f16(const void* A, const void* B, const void* dC, void* 
                             int32_t dtype, int32_t impl, void* ws, int64_t ws_bytes, void* stream);
 int spa3d_op_mlp_fused_f16(const void* na, const void* a, const void* w_in, const float* b_in, const void* w_out, const float* b_out, void* y,
                            void* h, void* hpre, int64_t M, int32_t d, int32_t mlp, int32_t dtype, void* ws, int64_t ws_bytes, void* stream);
+int spa3d_op_qkv_attention_f16(const void* nq, int64_t ldn, const void* wq, const void* wk, const void* wv, const float* scale_q, const float* scale_k,
+                               const float* keymask, const int32_t* seq_off, int64_t nseq, int32_t S, int32_t H, void* qkv, void* o, float* lse,
+                               int32_t dtype, void* ws, int64_t ws_bytes, void* stream);
 int spa3d_op_layernorm_f16(const void* x, const float* scale, void* y, float* stats, int64_t rows, int32_t d, int32_t dtype, void* stream);
 int spa3d_op_layernorm_bwd_f16(const void* x, const float* scale, const float* stats, const void* dy, void* dx, float* dscale, int64_t rows,
                                int32_t d, int32_t dtype, void* stream);
@@ -110,6 +113,7 @@ int spa3d_op_attention_bwd_f16(const void* q, const void* k, const void* v, int6
 #define spa3d_op_linear_bwd spa3d_op_linear_bwd_f16
 #define spa3d_op_layernorm spa3d_op_layernorm_f16
 #define spa3d_op_mlp_fused spa3d_op_mlp_fused_f16
+#define spa3d_op_qkv_attention spa3d_op_qkv_attention_f16
 #define spa3d_op_layernorm_bwd spa3d_op_layernorm_bwd_f16
 #define spa3d_op_attention spa3d_op_attention_f16
 #define spa3d_op_attention_bwd spa3d_op_attention_bwd_f16
@@ -158,6 +162,19 @@ int spa3d_op_mlp_fused(const void* na, const void* a, const void* w_in, const fl
   if (c.ar.overflow) return SPA3D_ERR_WORKSPACE;
   mlp_fused_pack<bf16_t>(&c, (const bf16_t*)w_in, (const bf16_t*)w_out, wpk);
   if (!mlp_fused_fwd(&c, (const bf16_t*)na, (const bf16_t*)a, (bf16_t*)y, (bf16_t*)h, (bf16_t*)hpre, M, d, mlp, wpk, b_in, b_out)) return SPA3D_ERR_ARG;
+  return c.status();
+}
+
+int spa3d_op_qkv_attention(const void* nq, int64_t ldn, const void* wq, const void* wk, const void* wv, const float* scale_q, const float* scale_k,
+                           const float* keymask, const int32_t* seq_off, int64_t nseq, int32_t S, int32_t H, void* qkv, void* o, float* lse,
+                           int32_t dtype, void* ws, int64_t ws_bytes, void* stream) {
+  FWD16(spa3d_op_qkv_attention_f16(nq, ldn, wq, wk, wv, scale_q, scale_k, keymask, seq_off, nseq, S, H, qkv, o, lse, dtype, ws, ws_bytes, stream))
+  if (!nq || !wq || !wk || !wv || !scale_q || !scale_k || !qkv || !o || dtype == SPA3D_F32 || H < 1 || H > 64) return SPA3D_ERR_ARG;
+  OpCtx c(stream, ws, ws_bytes);
+  bf16_t* wpk = c.alloc<bf16_t>(qkv_attn_pack_elems(H));
+  if (c.ar.overflow) return SPA3D_ERR_WORKSPACE;
+  qkv_attn_pack<bf16_t>(&c, (const bf16_t*)wq, (const bf16_t*)wk, (const bf16_t*)wv, H * 96, H, wpk);
+  if (!qkv_attn_fwd(&c, (const bf16_t*)nq, ldn, wpk, scale_q, scale_k, keymask, nseq, S, H, 96, 384, (bf16_t*)qkv, (bf16_t*)o, lse, seq_off, 0)) return SPA3D_ERR_ARG;
   return c.status();
 }
 

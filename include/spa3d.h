@@ -162,7 +162,8 @@ int spa3d_adamw_step(float* params, const float* grads, float* m, float* v, int6
  *                     single-buffer short-K kernel, 6 tiled GEMMs without the round-4 / round-5 kernels (MLP forward as two GEMMs, multi-pass input embedding, no row-stationary K = 384 kernel,
  *                     no large-register-tile dW kernel), 8 the product dispatch without the round-5 large-register-tile dW kernel, 9 = 3 with every divisible dW on that kernel.  (The `impl` argument of spa3d_op_linear* takes
  *                     the same values; spa3d_op_linear: | 16 = also write the pre-activation, the MLP-in form of the step.)
- *   "attn_impl"       0 product dispatch | 1 generic composition | 2 fused kernels | 3, 4 fused with the split-pass backward on 4 / 8 waves (tests)
+ *   "attn_impl"       0 product dispatch | 1 generic composition | 2 fused kernels | 3, 4 fused with the split-pass backward on 4 / 8 waves (tests) |
+ *                     6 fused kernels with the track encoder's QKV projection + attention forward as one launch (built in round 5, slower than the pair: opt-in)
  * and one test mode: "poison" 0/1 -- the workspace is filled with 16-bit NaN patterns before every sample chunk, so a read of a row that this
  * call has not written (the rounded-up tails of pruned GEMMs, chunk-to-chunk reuse of the bump allocator) shows up as NaN instead of as a
  * plausible stale value (tests/test_gpu_poison.py). */
@@ -243,6 +244,14 @@ int spa3d_op_layernorm(const void* x, const float* scale, void* y, float* stats,
                        int32_t dtype, void* stream);
 int spa3d_op_layernorm_bwd(const void* x, const float* scale, const float* stats, const void* dy, void* dx,
                            float* dscale /* f32[d], accumulated into */, int64_t rows, int32_t d, int32_t dtype, void* stream);
+
+/* QKV projection + attention core of ImprovedMHDPAttention as ONE kernel (attention.py:154-175; round 5): q | k | v = nq . (Wq | Wk | Wv) (16-bit, stored:
+ * qkv [rows, 3*H*96]), per-head RMSNorm of q and k, softmax, PV -> o [rows, H*96], lse [nseq, H, S, 2] (may be NULL).  nq [rows, 384] with row stride ldn;
+ * wq / wk / wv [384, H*96] in the activation type; d = 384 and Dh = 96 only, S <= 160.  seq_off (int32 [nseq + 1], device) = ragged sequences (token pruning) or
+ * NULL for nseq dense sequences of S rows; keymask as spa3d_op_attention.  16-bit dtypes only; SPA3D_ERR_ARG when the shape is not covered. */
+int spa3d_op_qkv_attention(const void* nq, int64_t ldn, const void* wq, const void* wk, const void* wv, const float* scale_q, const float* scale_k,
+                           const float* keymask, const int32_t* seq_off, int64_t nseq, int32_t S, int32_t H, void* qkv, void* o, float* lse,
+                           int32_t dtype, void* ws, int64_t ws_bytes, void* stream);
 
 /* Multi-head attention core of ImprovedMHDPAttention (attention.py:166-175): per-head RMSNorm of
  * q and k (scales f32[Dh]), q/sqrt(Dh), key mask (f32 [nseq,Sk] or NULL, non-zero = keep),
