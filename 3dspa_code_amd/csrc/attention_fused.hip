@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void xattn_dq_finish_kernel(const float* __res
   }
   red[w][lane] = a0; if (hi) red[w][64 + lane] = a1;
   __syncthreads();
-  if (tid < DH) atomicAdd(dsq + tid, red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+  if (tid < DH) grad_add(dsq + tid, red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
 }
 
 static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -787,11 +787,17 @@ __device__ __forceinline__ void flush_scale_grads(const AttnBwdArgs& g, float* s
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
       if (fr == 0) {
-        if (has_q) atomicAdd(sred + dt * 16 + fq * 4 + r, a);
-        if (has_k) atomicAdd(sred + DH + dt * 16 + fq * 4 + r, b);
+        if (det_on()) {  // deterministic mode: LDS float atomics depend on arrival order too -- every wave adds straight into the fixed-point shadow
+          if (has_q) grad_add(g.dsq + dt * 16 + fq * 4 + r, a);
+          if (has_k) grad_add(g.dsk + dt * 16 + fq * 4 + r, b);
+        } else {
+          if (has_q) atomicAdd(sred + dt * 16 + fq * 4 + r, a);
+          if (has_k) atomicAdd(sred + DH + dt * 16 + fq * 4 + r, b);
+        }
       }
     }
   __syncthreads();
+  if (det_on()) return;
   if (tid < DH) atomicAdd(g.dsq + tid, sred[tid]);
   else if (tid < 2 * DH) atomicAdd(g.dsk + tid - DH, sred[tid]);
 }
@@ -1162,4 +1168,5 @@ bool attn_fused_bwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const b
   SPA_LAUNCH_CHECK(c);
   return true;
 }
+SPA_DET_UPLOAD_DEF(det_upload_attn)
 }  // namespace SPA_NS

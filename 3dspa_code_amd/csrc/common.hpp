@@ -93,6 +93,34 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- deterministic parameter gradients (spa3d_set_option "det_grads").  Every reduction INTO the flat gradient buffer (split-M dW tiles, bias / scale column sums,
+// broadcast gradients) is a float atomic by default: fast, and its result depends on arrival order in the last bits.  In this mode the same call sites add 64-bit FIXED-POINT
+// integers (2^-32 units: exact, order-independent) into a shadow of the gradient buffer, which det_flush adds to the float buffer once a range is final.  The switch is a
+// per-translation-unit device variable (no relocatable device code here), uploaded by det_upload_* at the start of a call; nullptr = float atomics.
+struct DetCfg { float* gbase; long long* shadow; long long n; unsigned* flag; };
+static __device__ DetCfg det_cfg_dev;
+__device__ __forceinline__ bool det_on() { return det_cfg_dev.shadow != nullptr; }
+__device__ __forceinline__ void grad_add(float* p, float v) {
+  long long* sh = det_cfg_dev.shadow;
+  if (sh) {
+    const long long i = p - det_cfg_dev.gbase;
+    if ((unsigned long long)i < (unsigned long long)det_cfg_dev.n) {
+      const float f = v * 4294967296.f;
+      if (fabsf(f) < 9.0e18f) atomicAdd((unsigned long long*)(sh + i), (unsigned long long)__float2ll_rn(f));   // NaN fails the comparison too
+      else atomicOr(det_cfg_dev.flag, 1u);                                                                      // sticky: det_flush then writes NaN
+      return;
+    }
+  }
+  atomicAdd(p, v);
+}
+#define SPA_DET_UPLOAD_DEF(fn) \
+  void fn(hipStream_t st_, const DetCfg* d) { (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(det_cfg_dev), d, sizeof(DetCfg), 0, hipMemcpyHostToDevice, st_); }
+void det_upload_kernels(hipStream_t, const DetCfg*);
+void det_upload_gemm_fast(hipStream_t, const DetCfg*);
+void det_upload_gemm_tnb(hipStream_t, const DetCfg*);
+void det_upload_gemm_generic(hipStream_t, const DetCfg*);
+void det_upload_attn(hipStream_t, const DetCfg*);
+
 }  // namespace SPA_NS
 
 // ------------------------------------------------------------------------------------------
@@ -170,6 +198,9 @@ struct spa3d_ctx {
   int rs_gemm = 1;        // K = 384 projections on the row-stationary kernel (gemm_rs.hip); gemm_impl 6 = the tiled kernels; 7 (ops) = required
   int qkv_attn = 0;       // track-encoder QKV projection + attention forward as ONE kernel (qkv_attn.hip): built and measured in round 5, 1.47x SLOWER than the
                           // projection GEMM + attention kernel pair (profiles/r05_qkv_attn_fused.log), so opt-in only: attn_impl 6
+  int det_grads = 0;      // spa3d_set_option "det_grads": order-independent parameter gradients (fixed-point shadow accumulation, DetCfg above); costs a few %
+  int det_uploaded = 0;   // the device-side switch currently holds a live shadow (must be cleared by the next call that runs without it)
+  SPA_NS::DetCfg det_host = {nullptr, nullptr, 0, nullptr};  // what was uploaded last (kept alive for the asynchronous copy)
   int poison = 0;         // spa3d_set_option "poison": NaN-fill the workspace before every chunk and every op output before its launch (tests)
   bool tn_colsum_fused = false;  // set by gemm_tn_bf16: the last call also produced GemmDesc::colsum_out
   Prof prof;
@@ -349,6 +380,7 @@ void k_loss_finalize(spa3d_ctx*, const float* sums, const unsigned* poison, cons
 void k_adamw(spa3d_ctx*, float* p, const float* g, float* m, float* v, int64_t n, float lr, int64_t step, float clip, float b1, float b2,
              float eps, float wd, float* scratch);
 void k_uniform_noise(spa3d_ctx*, float* out, int64_t n, uint32_t k0, uint32_t k1);
+void k_det_flush(spa3d_ctx*, float* g, long long* shadow, const unsigned* flag, int64_t n);  // g[i] += shadow[i] * 2^-32; shadow[i] = 0; NaN when *flag
 // single-query attention of the pruned last block (kernels.hip)
 template <typename T> void k_attn_q1_fwd(spa3d_ctx*, const T* q0, int64_t ldq0, const T* k, const T* v, int64_t ldk, int64_t ldv,
                                          const float* sq, const float* sk, const float* km, int64_t nseq, int S, int H, int Dh, T* o0,

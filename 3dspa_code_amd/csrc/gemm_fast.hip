@@ -1186,7 +1186,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int gi = i0 + wi + i * 32 + (r & 3) + 8 * (r >> 2) + rb;
-        if (gi < g.Ki && gn < g.N) atomicAdd(g.C + (int64_t)gi * g.ldc + gn, acc[i][j][r]);
+        if (gi < g.Ki && gn < g.N) grad_add(g.C + (int64_t)gi * g.ldc + gn, acc[i][j][r]);
       }
     }
 }
@@ -1370,7 +1370,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs g) {
     for (int j = 0; j < WNT; ++j) {
       const float t = cs[j] + __shfl_xor(cs[j], 32, 64);
       const int gn = n0 + wc * (WNT * 32) + j * 32 + (lane & 31);
-      if (lane < 32 && gn < g.N) atomicAdd(g.colsum + gn, t);
+      if (lane < 32 && gn < g.N) grad_add(g.colsum + gn, t);
     }
   }
   // ---- epilogue: 32x32 C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); one register = two 128-B row segments
@@ -1386,7 +1386,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int gi = i0 + wr * (WIT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rb;
-        if (gi < g.Ki && gn < g.N) atomicAdd(cb + (int64_t)gi * g.ldc + cn, acc[i][j][r]);
+        if (gi < g.Ki && gn < g.N) grad_add(cb + (int64_t)gi * g.ldc + cn, acc[i][j][r]);
       }
     }
 }
@@ -1481,4 +1481,5 @@ bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d) {
   SPA_LAUNCH_CHECK(c);
   return true;
 }
+SPA_DET_UPLOAD_DEF(det_upload_gemm_fast)
 }  // namespace SPA_NS

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs g) {
         }
         if (g.out_f32) {
           float* cp = (float*)g.C + ci;
-          if (g.atomic) atomicAdd(cp, v);
+          if (g.atomic) grad_add(cp, v);
           else if (g.accumulate) *cp += v;
           else *cp = v;
         } else {
@@ -194,4 +194,5 @@ void gemm_generic(spa3d_ctx* c, const GemmDesc& d) {
 }
 template void gemm_generic<float>(spa3d_ctx*, const GemmDesc&);
 template void gemm_generic<bf16_t>(spa3d_ctx*, const GemmDesc&);
+SPA_DET_UPLOAD_DEF(det_upload_gemm_generic)
 }  // namespace SPA_NS

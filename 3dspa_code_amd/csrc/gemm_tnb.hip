@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tnb_kernel(TnArgs g) {
       for (int k = 0; k < (WB ? 2 : 3); ++k) {
         const float t = cs[k] + __shfl_xor(cs[k], 32, 64);
         const int gn = n0 + (WB ? 32 * (2 * w + k) : 96 * w + 32 * k) + (lane & 31);
-        if (lane < 32) atomicAdd(g.colsum + gn, t);
+        if (lane < 32) grad_add(g.colsum + gn, t);
       }
     }
   }
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tnb_kernel(TnArgs g) {
     for (int r = 0; r < 16; ++r) {
       float v;
       if constexpr (t < 16) v = accA[t][r]; else v = accV[t - 16][r];
-      atomicAdd(p0 + (int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc, v);
+      grad_add(p0 + (int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc, v);
     }
   });
 }
@@ -269,8 +269,8 @@ __global__ __launch_bounds__(256) void gemm_tn_tail_kernel(TnArgs g, int64_t m0,
   }
   float* cb = g.C; int cn = n;
   if (g.seg_n > 0) { const int sg = n / g.seg_n; if (sg > 0) { cb = g.Cseg[sg > 1]; cn -= sg * g.seg_n; } }
-  atomicAdd(cb + (int64_t)i * g.ldc + cn, s);
-  if (g.colsum && i == 0) atomicAdd(g.colsum + n, sb);
+  grad_add(cb + (int64_t)i * g.ldc + cn, s);
+  if (g.colsum && i == 0) grad_add(g.colsum + n, sb);
 }
 
 template <bool WB, bool CS, bool REMAP>
@@ -322,4 +322,5 @@ bool gemm_tnb(spa3d_ctx* c, TnArgs g) {
   return true;
 }
 
+SPA_DET_UPLOAD_DEF(det_upload_gemm_tnb)
 }  // namespace SPA_NS

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
         int i = lane + 64 * (j0 + j);
         if (i < d) {
           float s = red[0][j * 64 + lane] + red[1][j * 64 + lane] + red[2][j * 64 + lane] + red[3][j * 64 + lane];
-          atomicAdd(dscale + i, s);
+          grad_add(dscale + i, s);
         }
       }
     }
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void ln_bwd_part_kernel(const T* __restrict__ 
       if (lane < LPR) red[w][(sub + LPR * c) * NV + j] = a;
     }
   __syncthreads();
-  for (int t = threadIdx.x; t < DV; t += 256) atomicAdd(dscale + t, red[0][t] + red[1][t] + red[2][t] + red[3][t]);
+  for (int t = threadIdx.x; t < DV; t += 256) grad_add(dscale + t, red[0][t] + red[1][t] + red[2][t] + red[3][t]);
 }
 template <typename T>
 void k_layernorm(spa3d_ctx* c, const T* x, const float* scale, T* y, float* stats, int64_t rows, int d) {
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const T* __restrict__ x
       if (c < nch)
 #pragma unroll
         for (int j = 0; j < NV; ++j)
-          atomicAdd(dscale + c * NV + j, red[0][lane * NV + j] + red[1][lane * NV + j] + red[2][lane * NV + j] + red[3][lane * NV + j]);
+          grad_add(dscale + c * NV + j, red[0][lane * NV + j] + red[1][lane * NV + j] + red[2][lane * NV + j] + red[3][lane * NV + j]);
     }
   }
 }
@@ -464,8 +464,8 @@ __global__ __launch_bounds__(256) void rms_heads_bwd_kernel(const T* __restrict_
   red[w][lane] = a0; red[w][lane + 64] = a1;
   __syncthreads();
   if (w == 0) {
-    if (lane < Dh) atomicAdd(dscale + lane, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
-    if (lane + 64 < Dh) atomicAdd(dscale + lane + 64, red[0][lane + 64] + red[1][lane + 64] + red[2][lane + 64] + red[3][lane + 64]);
+    if (lane < Dh) grad_add(dscale + lane, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+    if (lane + 64 < Dh) grad_add(dscale + lane + 64, red[0][lane + 64] + red[1][lane + 64] + red[2][lane + 64] + red[3][lane + 64]);
   }
 }
 template <typename T>
@@ -681,7 +681,7 @@ __global__ void colsum_kernel(const T* __restrict__ x, int64_t rows, int n, int6
   }
   red[w][threadIdx.x & 63] = s;
   __syncthreads();
-  if (w == 0 && col < n) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (w == 0 && col < n) grad_add(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 // vectorised: a thread owns one 16-byte column chunk and walks rows; block = 32 chunks x 8 row lanes
 template <typename T>
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x
       float s_ = 0.f;
 #pragma unroll
       for (int k = 0; k < 8; ++k) s_ += red[k][cx * NV + j];
-      atomicAdd(out + ch * NV + j, s_);
+      grad_add(out + ch * NV + j, s_);
     }
 }
 template <typename T>
@@ -1221,7 +1221,7 @@ __global__ void bcast_grad_kernel(const T* __restrict__ dsrc, int64_t per, int64
   }
   for (; b < b1; ++b) s0 += ld(dsrc + b * bstride + i);
   const float s = (s0 + s1) + (s2 + s3);
-  if (gridDim.y == 1) dparam[i] += s; else atomicAdd(dparam + i, s);
+  if (gridDim.y == 1) dparam[i] += s; else grad_add(dparam + i, s);
 }
 // dparam[per] += sum_b dsrc[b*bstride + :per]   (B up to ~10^5 strided rows: split over blockIdx.y, one f32 atomic per column per slice)
 template <typename T> void k_bcast_grad(spa3d_ctx* c, const T* dsrc, int64_t per, int64_t B, int64_t bstride, float* dparam) {
@@ -1337,9 +1337,9 @@ __global__ void rank_bwd_kernel(const T* __restrict__ x, const T* __restrict__ d
   }
   __syncthreads();
   for (int t = threadIdx.x; t < N; t += 256) {
-    if (gb) atomicAdd(gb + t, rb[t]);
+    if (gb) grad_add(gb + t, rb[t]);
 #pragma unroll
-    for (int k = 0; k < K; ++k) atomicAdd(gw + (int64_t)k * N + t, rw[k * N + t]);
+    for (int k = 0; k < K; ++k) grad_add(gw + (int64_t)k * N + t, rw[k * N + t]);
   }
 }
 template <typename T>
@@ -1358,6 +1358,7 @@ bool k_rank_fwd(spa3d_ctx* c, const T* x, const T* w, const float* bias, T* out,
 }
 template <typename T>
 bool k_rank_bwd(spa3d_ctx* c, const T* x, const T* dy, int64_t M, int N, int K, int64_t ldy, int rgroup, int rskip, float* gw, float* gb) {
+  if (c->det_grads) return false;  // its workgroup-level reduction uses LDS float atomics (arrival order): the deterministic mode takes the GEMM path
   if (K < 1 || K > 4 || N % 8 || N / 8 > 256 || ldy % 8 || (((uintptr_t)dy) & 15) || M >= 0x7fffffffLL) return false;
   if (c->dry || M == 0) return true;
   const int64_t rpb = std::max<int64_t>(256, cdiv(M, 1024));
@@ -1380,8 +1381,8 @@ __global__ void discretize_kernel(const float* __restrict__ lat, const float* __
                                   float* __restrict__ clipmask, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float raw = lat[i];
-    float l = fminf(fmaxf(raw, -1.f), 1.f);
-    if (clipmask) clipmask[i] = (raw >= -1.f && raw <= 1.f) ? 1.f : 0.f;
+    float l = raw != raw ? raw : fminf(fmaxf(raw, -1.f), 1.f);   // jnp.clip keeps a NaN a NaN (fmaxf / fminf would return the bound): a diverged latent must show
+    if (clipmask) clipmask[i] = raw != raw ? raw : ((raw >= -1.f && raw <= 1.f) ? 1.f : 0.f);   // ... in the backward as well (jnp.clip's gradient of NaN is NaN)
     if (disc) {
       float q = rintf(__fmul_rn(l, 128.f)) / 128.f;
       q = __fsub_rn(__fadd_rn(q, noise[i] / 128.f), 1.0f / 256.0f);
@@ -1766,6 +1767,18 @@ __global__ void uniform_noise_kernel(float* __restrict__ out, int64_t n, int64_t
     if (half + j < n) out[half + j] = __uint_as_float((x1 >> 9) | 0x3F800000u) - 1.0f;
   }
 }
+// deterministic mode: fold the fixed-point shadow of a range of the gradient buffer into it (and clear the shadow: a later flush of the same range adds nothing)
+__global__ __launch_bounds__(256) void det_flush_kernel(float* __restrict__ g, long long* __restrict__ shadow, const unsigned* __restrict__ flag, int64_t n) {
+  const bool bad = *flag != 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const long long q = shadow[i];
+    if (q != 0 || bad) { g[i] = bad ? __int_as_float(0x7fc00000) : g[i] + (float)((double)q * (1.0 / 4294967296.0)); shadow[i] = 0; }
+  }
+}
+void k_det_flush(spa3d_ctx* c, float* g, long long* shadow, const unsigned* flag, int64_t n) {
+  if (c->dry || n <= 0) return;
+  det_flush_kernel<<<(unsigned)std::min<int64_t>(cdiv(n, 256), 8192), 256, 0, c->stream>>>(g, shadow, flag, n); SPA_LAUNCH_CHECK(c);
+}
 void k_uniform_noise(spa3d_ctx* c, float* out, int64_t n, uint32_t k0, uint32_t k1) {
   if (c->dry || n == 0) return;
   int64_t half = (n + (n & 1)) / 2;
@@ -2075,8 +2088,9 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
 #pragma unroll
       for (int j = 0; j < CC; ++j) {
         const float dqh = u[j] * skl[j];
-        atomicAdd(&red[1][part * CC + j], qs[j] * u[j]);
-        atomicAdd(&red[0][part * CC + j], dqh * xq[j]);
+        // (deterministic mode: LDS float atomics depend on arrival order too -- every contribution goes straight to the fixed-point shadow)
+        if (det_on()) { const int ch_ = q1_chan<T, CC>(j, part, vec); grad_add(dsk + ch_, qs[j] * u[j]); grad_add(dsq + ch_, dqh * xq[j]); }
+        else { atomicAdd(&red[1][part * CC + j], qs[j] * u[j]); atomicAdd(&red[0][part * CC + j], dqh * xq[j]); }
         xq[j] = rq * (dqh * sql[j] - xq[j] * gq);
       }
       q1_store<T, CC>(dq0 + seq * (int64_t)H * Dh + h * Dh, vec, xq, part);
@@ -2086,8 +2100,7 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
   for (int t = threadIdx.x; t < 4 * CC; t += 256) {
     const int pt = t / CC, j = t - pt * CC;
     const int ch = q1_chan<T, CC>(j, pt, vec);
-    atomicAdd(dsq + ch, red[0][t]);
-    atomicAdd(dsk + ch, red[1][t]);
+    if (!det_on()) { atomicAdd(dsq + ch, red[0][t]); atomicAdd(dsk + ch, red[1][t]); }
   }
 }
 template <typename T>
@@ -2182,4 +2195,5 @@ template void k_vis_mean_pool<float>(spa3d_ctx*, const float*, const float*, int
 template void k_vis_mean_pool<bf16_t>(spa3d_ctx*, const bf16_t*, const float*, int64_t, int, int, bf16_t*);
 template void k_vis_mean_pool_bwd<float>(spa3d_ctx*, const float*, const float*, int64_t, int, int, float*);
 template void k_vis_mean_pool_bwd<bf16_t>(spa3d_ctx*, const bf16_t*, const float*, int64_t, int, int, bf16_t*);
+SPA_DET_UPLOAD_DEF(det_upload_kernels)
 }  // namespace SPA_NS

@@ -664,11 +664,13 @@ template <typename T> struct Net {
   // each is recorded on the launch stream when its segment of the flat gradient buffer (spa3d_grad_segments) has received its last
   // contribution; the third segment (embedding, track encoder, state_init leaves) is final when the call's work is.  With a loss scale (fp16) a
   // finished segment is unscaled right before its event; the rest of the buffer at the end of the call.
+  long long* det_shadow = nullptr; const unsigned* det_flag = nullptr;   // deterministic mode: the fixed-point shadow of G (common.hpp DetCfg)
   int64_t seg_lo[2] = {0, 0}, seg_hi[2] = {0, 0};  // flat ranges of segment 0 ([b2, n): readout side) and 1 ([b1, b2): latent stacks), spa3d_grad_segments
   const float* scale_dev = nullptr;                  // fp16 mode: the call's loss scale (device)
   bool seg_unscaled[2] = {false, false};
   void grad_segment_done(int i) {
     if (c->dry || !c->last_chunk || !c->grad_ev[i]) return;
+    if (det_shadow && seg_hi[i] > seg_lo[i]) k_det_flush(c, G + seg_lo[i], det_shadow + seg_lo[i], det_flag, seg_hi[i] - seg_lo[i]);   // the segment's shadow sums are final too
     if (c->loss_scale != 1.f) {  // fp16: bring the finished segment back to true scale NOW (a power of two: exact) so that its all-reduce can start behind the event
       if (!scale_dev || seg_hi[i] <= seg_lo[i]) return;
       k_unscale(c, G + seg_lo[i], scale_dev, seg_hi[i] - seg_lo[i]);
@@ -801,10 +803,22 @@ void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
     if (c->loss_scale != 1.f) k_set_loss_scale(c, denom_dev, L1_WEIGHT, c->loss_scale, denom_dev + 1);  // sums[7]
     if (!a.accumulate) k_zero(c, a.G, c->nparams * 4);
   }
-  if (train && c->loss_scale != 1.f) {
+  if (train && (c->loss_scale != 1.f || c->det_grads)) {
     int64_t b4[4];
     if (spa3d_grad_segments(c, b4) == SPA3D_OK) { net.seg_lo[0] = b4[2]; net.seg_hi[0] = b4[3]; net.seg_lo[1] = b4[1]; net.seg_hi[1] = b4[2]; }
-    net.scale_dev = denom_dev + 1;
+    if (c->loss_scale != 1.f) net.scale_dev = denom_dev + 1;
+  }
+  // deterministic parameter gradients: every reduction into G goes through a 64-bit fixed-point shadow (common.hpp DetCfg, grad_add)
+  if (train && c->det_grads) {
+    long long* sh = net.template alloc<long long>(c->nparams); unsigned* fl = net.template alloc<unsigned>(64);
+    k_zero(c, sh, c->nparams * 8); k_zero(c, fl, 256);
+    net.det_shadow = sh; net.det_flag = fl;
+    c->det_host = DetCfg{a.G, sh, (long long)c->nparams, fl};
+  } else c->det_host = DetCfg{nullptr, nullptr, 0, nullptr};
+  if (!c->dry && (c->det_uploaded || c->det_host.shadow)) {
+    det_upload_kernels(c->stream, &c->det_host); det_upload_gemm_fast(c->stream, &c->det_host); det_upload_gemm_tnb(c->stream, &c->det_host);
+    det_upload_gemm_generic(c->stream, &c->det_host); det_upload_attn(c->stream, &c->det_host);
+    c->det_uploaded = c->det_host.shadow != nullptr;
   }
   // The ragged chunk (B % Bc samples) runs FIRST, so the last chunk -- the one under whose track-encoder backward the gradient segments are all-reduced -- is a
   // full one (B = 64, Bc = 9: 9 samples of encoder backward to hide behind instead of 1)
@@ -840,6 +854,7 @@ void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
     }
     c->ar.release(mk);
   }
+  if (net.det_shadow) k_det_flush(c, a.G, net.det_shadow, net.det_flag, c->nparams);   // what the segment flushes left (flushed ranges hold zeros)
   if (train && c->loss_scale != 1.f) {  // fp32 gradient buffer back to true scale (exact: power of two); segments already unscaled at their events are skipped
     const int64_t lo1 = net.seg_lo[1], lo0 = net.seg_lo[0];
     if (!net.seg_unscaled[0] && !net.seg_unscaled[1]) k_unscale(c, a.G, denom_dev + 1, c->nparams);
@@ -1009,6 +1024,7 @@ int spa3d_create(const spa3d_config* cfg, spa3d_handle* out) {
   e = getenv("SPA3D_PRUNE"); if (e) c->prune = atoi(e);
   e = getenv("SPA3D_RO_SHARE"); if (e) c->ro_share = atoi(e);
   e = getenv("SPA3D_CHUNK"); if (e) c->chunk = atoi(e);
+  e = getenv("SPA3D_DET_GRADS"); if (e) c->det_grads = atoi(e) != 0;
   *out = c;
   return SPA3D_OK;
 }
@@ -1090,6 +1106,7 @@ int spa3d_set_option(spa3d_handle h, const char* name, double value) {
   else if (n == "gemm_impl") apply_gemm_impl(h, (int)value);
   else if (n == "chunk") h->chunk = value > 0 ? (int)value : 0;
   else if (n == "poison") h->poison = value != 0;
+  else if (n == "det_grads") h->det_grads = value != 0;
   else { h->err = "unknown option: " + n; return SPA3D_ERR_ARG; }
   return SPA3D_OK;
 }

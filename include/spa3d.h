@@ -151,7 +151,7 @@ int spa3d_adamw_step(float* params, const float* grads, float* m, float* v, int6
                      int64_t step, float clip, float b1, float b2, float eps, float wd,
                      float* scratch, void* stream);
 
-/* Per-handle switches -- the only ones the library has; each may be preset at spa3d_create from the environment variable of the same name in
+/* Per-handle switches -- the only ones the library has (seven + one test mode); each may be preset at spa3d_create from the environment variable of the same name in
  * capitals with an SPA3D_ prefix (SPA3D_PRUNE ...).  Unknown names return SPA3D_ERR_ARG.
  *   "prune"      0/1  token pruning of the track encoder (16-bit modes)            } with both 0 every entry point is fully asynchronous
  *   "ro_share"   0/1  shared latent rows of the first readout block (16-bit modes) } (no plan count is read back)
@@ -164,6 +164,10 @@ int spa3d_adamw_step(float* params, const float* grads, float* m, float* v, int6
  *                     the same values; spa3d_op_linear: | 16 = also write the pre-activation, the MLP-in form of the step.)
  *   "attn_impl"       0 product dispatch | 1 generic composition | 2 fused kernels | 3, 4 fused with the split-pass backward on 4 / 8 waves (tests) |
  *                     6 fused kernels with the track encoder's QKV projection + attention forward as one launch (built in round 5, slower than the pair: opt-in)
+ *   "det_grads"  0/1  order-independent parameter gradients: every reduction into the gradient buffer (split-M dW tiles, bias / scale column sums, broadcast
+ *                     gradients) adds 64-bit fixed-point integers (2^-32 units) into a shadow of the buffer instead of float atomics, so two runs -- and two
+ *                     data-parallel schedules -- give the same bits.  Costs 8 bytes of workspace per parameter and ~13 % of the step at BASELINE configs[2]
+ *                     (1.87 -> 2.12 s: 64-bit atomics in the dW epilogues, the 1-channel depth gradient on the GEMM path); off by default.
  * and one test mode: "poison" 0/1 -- the workspace is filled with 16-bit NaN patterns before every sample chunk, so a read of a row that this
  * call has not written (the rounded-up tails of pruned GEMMs, chunk-to-chunk reuse of the bump allocator) shows up as NaN instead of as a
  * plausible stale value (tests/test_gpu_poison.py). */

@@ -90,8 +90,8 @@ def test_hip_trainstate_world2_equals_the_full_batch_step(tmp_path):
   assert abs(a['gn'] - b['gn']) <= 1e-4 * abs(a['gn'])
 
 
-@pytest.mark.parametrize('prec,batch,chunk', [('fp32', 4, 1), ('fp32', 6, 2), ('fp16', 6, 2)])
-def test_hip_trainstate_world2_several_chunks_overlap_on_and_off(tmp_path, prec, batch, chunk):
+@pytest.mark.parametrize('prec,batch,chunk,det', [('fp32', 4, 1, 0), ('fp32', 6, 2, 0), ('fp16', 6, 2, 0), ('fp32', 6, 2, 1), ('fp16', 6, 2, 1)])
+def test_hip_trainstate_world2_several_chunks_overlap_on_and_off(tmp_path, prec, batch, chunk, det):
   """Several sample chunks per rank, so parameter gradients ACCUMULATE across chunks and the segment events of the overlapped all-reduce (include/spa3d.h,
   spa3d_set_grad_events) must fire in the last chunk only.  (4, 1): B_local = 2 as 1 + 1.  (6, 2): B_local = 3 as 1 + 2 -- the RAGGED chunk runs first, the
   last chunk is a full one (csrc/model.hip run_body).  fp16: the loss-scaled buffer is unscaled per segment right before the segment's event, so BASELINE
@@ -101,7 +101,7 @@ def test_hip_trainstate_world2_several_chunks_overlap_on_and_off(tmp_path, prec,
   outs = {}
   for tag, world, env in (('full', 1, {}), ('ov1', 2, {'SPA3D_DP_OVERLAP': '1'}), ('ov0', 2, {'SPA3D_DP_OVERLAP': '0'})):
     o = str(tmp_path / (tag + '.pt'))
-    r = _launch(world, o, _port(), BATCH=str(batch), SPA3D_CHUNK=str(chunk), PREC=prec, **env)
+    r = _launch(world, o, _port(), BATCH=str(batch), SPA3D_CHUNK=str(chunk), PREC=prec, SPA3D_DET_GRADS=str(det), **env)
     assert all(rc == 0 for rc, _ in r), '\n'.join(x[-2000:] for _, x in r)
     outs[tag] = [torch.load(o + '.rank%d' % k, weights_only=True) for k in range(world)]
   assert outs['ov1'][0]['overlap'] and not outs['ov0'][0]['overlap']
@@ -110,6 +110,8 @@ def test_hip_trainstate_world2_several_chunks_overlap_on_and_off(tmp_path, prec,
   d01 = float((outs['ov1'][0]['flat'] - outs['ov0'][0]['flat']).abs().max())
   diff = float((outs['full'][0]['flat'] - outs['ov1'][0]['flat']).abs().max())
   print(f'{prec}, {batch} samples as 2 ranks x chunks of {chunk} vs one process: overlap on vs off max |param diff| {d01:.3e}; vs the full batch {diff:.3e}')
+  if det:  # det_grads (include/spa3d.h): order-independent gradient sums -> the overlapped and the stream-ordered all-reduce give the SAME bits (round 4 could only ask for 1e-5)
+    assert torch.equal(outs['ov1'][0]['flat'], outs['ov0'][0]['flat']) and outs['ov1'][0]['losses'] == outs['ov0'][0]['losses'], d01
   if prec == 'fp32':
     assert d01 < 1e-5 and all(abs(x - y) <= 1e-6 * abs(x) for x, y in zip(outs['ov1'][0]['losses'], outs['ov0'][0]['losses']))
     assert diff < 3e-5
