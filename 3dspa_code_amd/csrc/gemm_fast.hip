@@ -1422,7 +1422,7 @@ static void launch_tn8p_q(spa3d_ctx* c, TnArgs g, int rounds) {
 
 template <int WIT, int WNT>
 static void launch_tn8p(spa3d_ctx* c, const TnArgs& g, int rounds) {
-  launch_tn8p_q<WIT, WNT, 2>(c, g, rounds);  // two quarters per phase (+7-10 % over one: DESIGN.md 4, item 5)
+  launch_tn8p_q<WIT, WNT, 2>(c, g, rounds);  // two quarters per phase (+7-10 % over one: NOTEBOOK.md, "How the GEMMs got ...", item 5)
 }
 
 bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d) {

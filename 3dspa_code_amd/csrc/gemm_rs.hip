@@ -2,7 +2,7 @@
 // K/V projection of tracks_to_latents; dX = dY . W^T products whose contraction is 384 wide):   C[M, N] = A[M, 384] . W[384, N] (+ bias).
 //
 // These GEMMs move 768 B of A and 2 N B of C per row for 768 N FLOP: at N = 2304 the tiled 256x256 kernel spends MFMA time + the HBM time of
-// its 128-KB store burst per tile, in series ("What does not overlap").  Here the A rows never touch LDS and the stores never burst:
+// its 128-KB store burst per tile, in series (NOTEBOOK.md, "What does not overlap").  Here the A rows never touch LDS and the stores never burst:
 //   * persistent workgroup = 4 waves = one wave per SIMD; a wave owns 64 rows of a 256-row tile and holds them as 2 x 24 MFMA B fragments
 //     (192 registers) for the whole tile -- A is read from HBM exactly once, as rows;
 //   * W comes as a pre-packed stream of 1-KiB MFMA A fragments in consumption order (N / 64 segments of 48 KiB, L2-resident, identical for

@@ -14,7 +14,7 @@
 //   * h / hpre leave during the GEMM2 phases through the wave's own 12 KiB of the ring slot that phase refills, as whole 128-byte row pieces; y through the same scratch.
 // Phase = 48 MFMAs (32x32x16) on one 48-KiB ring slot: X_c = GEMM1 of hidden chunk c (ping-pong accumulators) with all eight gelu quads of chunk c-1 riding along,
 // Y_c = GEMM2 of chunk c-1 with that chunk's stores.  One barrier per phase; the LDS-DMA of segment p+2 is issued in phase p and waited for with a COUNTED vmcnt at the end
-// of phase p+1 (never 0 in the tile), so the h / hpre stores of a chunk have two phases to drain.  Measurements, ablations and what bounds it: DESIGN.md, "Round 4".
+// of phase p+1 (never 0 in the tile), so the h / hpre stores of a chunk have two phases to drain.  Measurements, ablations and what bounds it: NOTEBOOK.md, "Round 4".
 #include <cstdlib>
 
 #include "common.hpp"

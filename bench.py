@@ -16,7 +16,7 @@ T=150, xyz+depth+DINOv2-768, bf16) => weak scaling; configs[3] is exactly this a
 --config 2: configs[1] (xyz+depth only, C=4); --config 1: configs[0]'s shape (B=2, 64+16 tracks, T=24, xyz-only, fp32) on the GPU;
 --config 5: configs[4], the stress shape (8192 support + 2048 query, T = T_out = 300, C=772, fp16) with --batch samples per GPU (default 8:
 3.8 GB of input per sample).
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+Rank 0 prints ONE JSON line ("Measurement").
 """
 from __future__ import annotations
 

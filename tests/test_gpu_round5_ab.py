@@ -65,4 +65,4 @@ def test_large_tile_dw_kernel_equals_the_8_wave_kernels_in_model(precision, tmp_
   worst = max((rel_err(new[2][k], old[2][k]), k) for k in new[2] if float(old[2][k].double().norm()) > 0)
   print(f'{precision}: worst gradient leaf, large-tile vs 8-wave dW: {worst}')
   # fp32 accumulation of exact 16-bit products in both kernels; only the order of the fp32 sums (split-M atomics, 16-row quarters) differs
-  assert worst[0] < 5e-5, worst  # (run-to-run noise of the fp32 atomics in the scale / bias gradients alone is ~1e-5: DESIGN.md, deterministic reductions)
+  assert worst[0] < 5e-5, worst  # (run-to-run noise of the fp32 atomics in the scale / bias gradients alone is ~1e-5: DESIGN.md 4a)

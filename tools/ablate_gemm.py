@@ -1,7 +1,7 @@
 """Diagnostic only: the persistent NT GEMM with its output stores removed (a SEPARATE library built with -DSPA3D_ABLATE, never the
 product) = the loop-only rate, i.e. the ceiling of any scheme that hides the stores under the next tile's K-loop.
 (Round 2 also timed a persistent 128x256 instance this way -- the only tile whose finished rows fit in registers beside the next tile's
-accumulators: loop-only 995 TF/s at the QKV shape against 799 TF/s for the shipped 256x256 kernel WITH its stores, see DESIGN.md.)"""
+accumulators: loop-only 995 TF/s at the QKV shape against 799 TF/s for the shipped 256x256 kernel WITH its stores, see NOTEBOOK.md.)"""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,5 +1,5 @@
 """Diagnostic only: the 8-phase dW (TN) kernel with parts removed (SEPARATE libraries built with -DSPA3D_TN_ABL=mask, never the product; results of a masked
-build are wrong): 1 half of the transposed LDS reads, 2 no MFMAs.  Tests whether the kernel is bound by LDS read bandwidth ("what comes next").
+build are wrong): 1 half of the transposed LDS reads, 2 no MFMAs.  Tests whether the kernel is bound by LDS read bandwidth (NOTEBOOK.md, end of round 4).
     python tools/ablate_gemm_tn.py"""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

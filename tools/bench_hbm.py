@@ -1,5 +1,5 @@
 """HBM streaming rates on this box with library kernels (torch fill / copy / read-reduce): the practical ceilings the memory-bound
-classes are compared with (peak 8 TB/s; bench.py prices against the peak, DESIGN.md quotes these beside it)."""
+classes are compared with (peak 8 TB/s; bench.py prices against the peak, NOTEBOOK.md quotes these beside it)."""
 import torch
 def timeit(fn, n=10):
   fn(); torch.cuda.synchronize()
