@@ -99,22 +99,27 @@ __device__ __forceinline__ float wave_max(float v) {
 // per-translation-unit device variable (no relocatable device code here), uploaded by det_upload_* at the start of a call; nullptr = float atomics.
 struct DetCfg { float* gbase; long long* shadow; long long n; unsigned* flag; };
 static __device__ DetCfg det_cfg_dev;
+// A kernel with many additions loads the switch ONCE (det_load: scalar loads into SGPRs) and passes it along; re-reading the device variable at every addition cost the
+// large-tile dW kernel's 384-atomic epilogue and the single-query attention backward's inner loop 60 ms/step with the mode OFF (round 5, first version).
+__device__ __forceinline__ DetCfg det_load() { return det_cfg_dev; }
 __device__ __forceinline__ bool det_on() { return det_cfg_dev.shadow != nullptr; }
-__device__ __forceinline__ void grad_add(float* p, float v) {
-  long long* sh = det_cfg_dev.shadow;
-  if (sh) {
-    const long long i = p - det_cfg_dev.gbase;
-    if ((unsigned long long)i < (unsigned long long)det_cfg_dev.n) {
+__device__ __forceinline__ void grad_add(const DetCfg& dc, float* p, float v) {
+  if (dc.shadow) {
+    const long long i = p - dc.gbase;
+    if ((unsigned long long)i < (unsigned long long)dc.n) {
       const float f = v * 4294967296.f;
-      if (fabsf(f) < 9.0e18f) atomicAdd((unsigned long long*)(sh + i), (unsigned long long)__float2ll_rn(f));   // NaN fails the comparison too
-      else atomicOr(det_cfg_dev.flag, 1u);                                                                      // sticky: det_flush then writes NaN
+      if (fabsf(f) < 9.0e18f) atomicAdd((unsigned long long*)(dc.shadow + i), (unsigned long long)__float2ll_rn(f));   // NaN fails the comparison too
+      else atomicOr(dc.flag, 1u);                                                                                    // sticky: det_flush then writes NaN
       return;
     }
   }
   atomicAdd(p, v);
 }
-#define SPA_DET_UPLOAD_DEF(fn) \
-  void fn(hipStream_t st_, const DetCfg* d) { (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(det_cfg_dev), d, sizeof(DetCfg), 0, hipMemcpyHostToDevice, st_); }
+__device__ __forceinline__ void grad_add(float* p, float v) { grad_add(det_load(), p, v); }   // cold sites: one addition per thread at a workgroup's end
+// (a one-thread kernel, not hipMemcpyToSymbolAsync: a copy from pageable host memory may block the host until the stream has drained)
+#define SPA_DET_UPLOAD_DEF(fn)                                                         \
+  __global__ void fn##_kernel(DetCfg d) { det_cfg_dev = d; }                           \
+  void fn(hipStream_t st_, const DetCfg* d) { fn##_kernel<<<1, 1, 0, st_>>>(*d); }
 void det_upload_kernels(hipStream_t, const DetCfg*);
 void det_upload_gemm_fast(hipStream_t, const DetCfg*);
 void det_upload_gemm_tnb(hipStream_t, const DetCfg*);

@@ -1178,6 +1178,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
   if (nt == 0) return;
   // ---- epilogue: 32x32 C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); one register = two 128-B row segments
   const int col = lane & 31, rb = 4 * (lane >> 5);
+  const DetCfg dc = det_load();   // deterministic-gradient switch (common.hpp), read once
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1186,7 +1187,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int gi = i0 + wi + i * 32 + (r & 3) + 8 * (r >> 2) + rb;
-        if (gi < g.Ki && gn < g.N) grad_add(g.C + (int64_t)gi * g.ldc + gn, acc[i][j][r]);
+        if (gi < g.Ki && gn < g.N) { float* pr = g.C + (int64_t)gi * g.ldc + gn; if (dc.shadow) grad_add(dc, pr, acc[i][j][r]); else atomicAdd(pr, acc[i][j][r]); }
       }
     }
 }
@@ -1375,6 +1376,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs g) {
   }
   // ---- epilogue: 32x32 C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); one register = two 128-B row segments
   const int col = lane & 31, rb = 4 * (lane >> 5);
+  const DetCfg dc = det_load();   // deterministic-gradient switch (common.hpp), read once
 #pragma unroll
   for (int i = 0; i < WIT; ++i)
 #pragma unroll
@@ -1386,7 +1388,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8p_kernel(TnArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int gi = i0 + wr * (WIT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + rb;
-        if (gi < g.Ki && gn < g.N) grad_add(cb + (int64_t)gi * g.ldc + cn, acc[i][j][r]);
+        if (gi < g.Ki && gn < g.N) { float* pr = cb + (int64_t)gi * g.ldc + cn; if (dc.shadow) grad_add(dc, pr, acc[i][j][r]); else atomicAdd(pr, acc[i][j][r]); }
       }
     }
 }

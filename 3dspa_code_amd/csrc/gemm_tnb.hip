@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tnb_kernel(TnArgs g) {
   }
   // ---- epilogue: 32x32 C/D map col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); one register = two 128-B row segments (the full-rate atomic shape)
   const int col = lane & 31, rb = 4 * (lane >> 5);
+  const DetCfg dc = det_load();   // deterministic-gradient switch (common.hpp), read once: nullptr = float atomics
   tn_for<0, 24>([&](auto t_) {
     constexpr int t = decltype(t_)::v; constexpr int j = t / 3, i = t % 3;
     const int it = WB ? 3 * w + i : j, jt = WB ? j : 3 * w + i;   // the tile's place in the workgroup tile
@@ -250,7 +251,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tnb_kernel(TnArgs g) {
     for (int r = 0; r < 16; ++r) {
       float v;
       if constexpr (t < 16) v = accA[t][r]; else v = accV[t - 16][r];
-      grad_add(p0 + (int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc, v);
+      float* pr = p0 + (int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc;
+      if (dc.shadow) grad_add(dc, pr, v); else atomicAdd(pr, v);
     }
   });
 }

@@ -1970,7 +1970,7 @@ void k_attn_q1_fwd(spa3d_ctx* c, const T* q0, int64_t ldq0, const T* k, const T*
 // With x^ the RMS-normalised rows, q^ = x^_q*s_q, k^ = x^_k*s_k and ds_k = p_k (dp_k - sum p dp) / sqrt(Dh):
 //   u = sum_k ds_k x^_k  gives both  dq^ = u*s_k  and  ds_k(scale) = q^*u;   dk^_k = ds_k q^;  dv_k = p_k dO.
 // Registers: q^, dO, u (+ one key row); the scales and the scale-gradient accumulators live in LDS.
-template <typename T, int CC>
+template <typename T, int CC, bool DET = false>  // DET: deterministic-gradient mode (common.hpp): the scale gradients accumulate as 64-bit fixed point, in LDS and in the shadow
 __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ q0, int64_t ldq0, const T* __restrict__ k, const T* __restrict__ v,
                                                           int64_t ldk, int64_t ldv, const float* __restrict__ sq, const float* __restrict__ sk,
                                                           const float* __restrict__ km, int64_t nprob, int Smax, int H,
@@ -1980,6 +1980,7 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
   __shared__ float dps[4][Q1_MAXS];
   __shared__ float scl[2][4 * CC];  // s_q, s_k in lane-channel order [part][j]
   __shared__ float red[2][4 * CC];  // block accumulators of d s_q, d s_k
+  __shared__ unsigned long long redq[DET ? 2 : 1][DET ? 4 * CC : 1];  // DET: the same in 2^-32 fixed point (integer LDS atomics do not depend on arrival order)
   constexpr int Dh = CC * 4;
   constexpr int NV = VecOf<T>::N;
   constexpr int G = (CC % NV == 0) ? NV : 1;  // output chunk; vec implies G == NV
@@ -1993,6 +1994,7 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
     const int pt = t / CC, j = t - pt * CC;
     const int ch = q1_chan<T, CC>(j, pt, vec);
     scl[0][t] = sq[ch]; scl[1][t] = sk[ch]; red[0][t] = 0.f; red[1][t] = 0.f;
+    if constexpr (DET) { redq[0][t] = 0ull; redq[1][t] = 0ull; }
   }
   __syncthreads();
   for (int64_t prob = (int64_t)blockIdx.x * 4 + wv; prob < nprob; prob += (int64_t)gridDim.x * 4) {
@@ -2089,8 +2091,10 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
       for (int j = 0; j < CC; ++j) {
         const float dqh = u[j] * skl[j];
         // (deterministic mode: LDS float atomics depend on arrival order too -- every contribution goes straight to the fixed-point shadow)
-        if (det_on()) { const int ch_ = q1_chan<T, CC>(j, part, vec); grad_add(dsk + ch_, qs[j] * u[j]); grad_add(dsq + ch_, dqh * xq[j]); }
-        else { atomicAdd(&red[1][part * CC + j], qs[j] * u[j]); atomicAdd(&red[0][part * CC + j], dqh * xq[j]); }
+        if constexpr (DET) {
+          atomicAdd(&redq[1][part * CC + j], (unsigned long long)__float2ll_rn(qs[j] * u[j] * 4294967296.f));
+          atomicAdd(&redq[0][part * CC + j], (unsigned long long)__float2ll_rn(dqh * xq[j] * 4294967296.f));
+        } else { atomicAdd(&red[1][part * CC + j], qs[j] * u[j]); atomicAdd(&red[0][part * CC + j], dqh * xq[j]); }
         xq[j] = rq * (dqh * sql[j] - xq[j] * gq);
       }
       q1_store<T, CC>(dq0 + seq * (int64_t)H * Dh + h * Dh, vec, xq, part);
@@ -2100,7 +2104,9 @@ __global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const T* __restrict__ 
   for (int t = threadIdx.x; t < 4 * CC; t += 256) {
     const int pt = t / CC, j = t - pt * CC;
     const int ch = q1_chan<T, CC>(j, pt, vec);
-    if (!det_on()) { atomicAdd(dsq + ch, red[0][t]); atomicAdd(dsk + ch, red[1][t]); }
+    if constexpr (DET) {  // (a non-finite partial saturates the conversion: the 16-bit dq / dk / dv beside it are NaN already and reach every upstream leaf)
+      grad_add(dsq + ch, (float)((double)(long long)redq[0][t] * (1.0 / 4294967296.0))); grad_add(dsk + ch, (float)((double)(long long)redq[1][t] * (1.0 / 4294967296.0)));
+    } else { atomicAdd(dsq + ch, red[0][t]); atomicAdd(dsk + ch, red[1][t]); }
   }
 }
 template <typename T>
@@ -2117,7 +2123,8 @@ void k_attn_q1_bwd(spa3d_ctx* c, const T* q0, int64_t ldq0, const T* k, const T*
   const int vec = (Dh % (4 * NV) == 0 && ldk % NV == 0 && ldv % NV == 0 && ldq0 % NV == 0 &&
                    ((((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)dk) | ((uintptr_t)dv) | ((uintptr_t)q0) | ((uintptr_t)d_o0) |
                      ((uintptr_t)dq0)) & 15) == 0) ? 1 : 0;
-#define Q1B(CCv) attn_q1_bwd_kernel<T, CCv><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, p0, d_o0, dq0, dk, dv, dsq, dsk, vec, seq_off)
+#define Q1B(CCv) do { if (c->det_grads) attn_q1_bwd_kernel<T, CCv, true><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, p0, d_o0, dq0, dk, dv, dsq, dsk, vec, seq_off); \
+                      else attn_q1_bwd_kernel<T, CCv, false><<<g, 256, 0, c->stream>>>(q0, ldq0, k, v, ldk, ldv, sq, sk, km, nprob, S, H, p0, d_o0, dq0, dk, dv, dsq, dsk, vec, seq_off); } while (0)
   switch (Dh / 4) { case 24: Q1B(24); break; case 16: Q1B(16); break; case 32: Q1B(32); break; case 8: Q1B(8); break; case 4: Q1B(4); break;
     case 2: Q1B(2); break; default: if (!c->hip_err) { c->hip_err = -3; c->err = "attn_q1: unsupported head width"; } return; }
 #undef Q1B

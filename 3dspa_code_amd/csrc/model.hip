@@ -815,7 +815,9 @@ void run_body(spa3d_ctx* c, const RunArgs& a, int Bc) {
     net.det_shadow = sh; net.det_flag = fl;
     c->det_host = DetCfg{a.G, sh, (long long)c->nparams, fl};
   } else c->det_host = DetCfg{nullptr, nullptr, 0, nullptr};
-  if (!c->dry && (c->det_uploaded || c->det_host.shadow)) {
+  // The switch lives in device variables shared by every handle of the process: EVERY train call states it, on its stream, before its first kernel -- a handle that
+  // left its (now dead) shadow pointer behind must never be what the next handle's kernels see (found by tests/test_gpu_poison.py running behind tests/test_gpu_det.py)
+  if (!c->dry && train) {
     det_upload_kernels(c->stream, &c->det_host); det_upload_gemm_fast(c->stream, &c->det_host); det_upload_gemm_tnb(c->stream, &c->det_host);
     det_upload_gemm_generic(c->stream, &c->det_host); det_upload_attn(c->stream, &c->det_host);
     c->det_uploaded = c->det_host.shadow != nullptr;

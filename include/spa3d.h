@@ -166,8 +166,8 @@ int spa3d_adamw_step(float* params, const float* grads, float* m, float* v, int6
  *                     6 fused kernels with the track encoder's QKV projection + attention forward as one launch (built in round 5, slower than the pair: opt-in)
  *   "det_grads"  0/1  order-independent parameter gradients: every reduction into the gradient buffer (split-M dW tiles, bias / scale column sums, broadcast
  *                     gradients) adds 64-bit fixed-point integers (2^-32 units) into a shadow of the buffer instead of float atomics, so two runs -- and two
- *                     data-parallel schedules -- give the same bits.  Costs 8 bytes of workspace per parameter and ~13 % of the step at BASELINE configs[2]
- *                     (1.87 -> 2.12 s: 64-bit atomics in the dW epilogues, the 1-channel depth gradient on the GEMM path); off by default.
+ *                     data-parallel schedules -- give the same bits.  Costs 8 bytes of workspace per parameter and ~3.6 % of the step at BASELINE configs[2]
+ *                     (1.82 -> 1.88 s: 64-bit atomics in the dW epilogues, the 1-channel depth gradient on the GEMM path); off by default.
  * and one test mode: "poison" 0/1 -- the workspace is filled with 16-bit NaN patterns before every sample chunk, so a read of a row that this
  * call has not written (the rounded-up tails of pruned GEMMs, chunk-to-chunk reuse of the bump allocator) shows up as NaN instead of as a
  * plausible stale value (tests/test_gpu_poison.py). */

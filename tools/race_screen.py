@@ -93,15 +93,16 @@ def run(REPS=40, verbose=True):
     dC = torch.randn(M, N, device='cuda', generator=g).bfloat16()
     Bd = torch.empty(K, N, device='cuda', dtype=torch.bfloat16)
     ref = (A.double().T @ dC.double())
-    worst = 0.0
-    for r in range(REPS):
-      dB = torch.full((K, N), float('nan'), device='cuda')
-      rc = lib.spa3d_op_linear_bwd(A.data_ptr(), Bd.data_ptr(), dC.data_ptr(), None, dB.data_ptr(), None, M, N, K, 1, 2, ws.data_ptr(), ws.numel(), s())
-      assert rc == 0
-      worst = max(worst, float((dB.double() - ref).abs().max() / ref.abs().max()))
-    ok = worst < 2e-5
-    bad += not ok
-    if verbose: print(f'TN M={M:7d} N={N:5d} Ki={K:5d}  worst max rel err over {REPS} runs {worst:.2e}  {"ok" if ok else "FAIL"}', flush=True)
+    for impl, kname in ((2, 'large register tile (round 5)'), (8, '8-wave kernels')):   # every shape here divides the 384 x 256 tile: impl 2 takes the large-tile kernel, 8 the 8-wave ones
+      worst = 0.0
+      for r in range(REPS):
+        dB = torch.full((K, N), float('nan'), device='cuda')
+        rc = lib.spa3d_op_linear_bwd(A.data_ptr(), Bd.data_ptr(), dC.data_ptr(), None, dB.data_ptr(), None, M, N, K, 1, impl, ws.data_ptr(), ws.numel(), s())
+        assert rc == 0
+        worst = max(worst, float((dB.double() - ref).abs().max() / ref.abs().max()))
+      ok = worst < 2e-5
+      bad += not ok
+      if verbose: print(f'TN M={M:7d} N={N:5d} Ki={K:5d} {kname:30s} worst max rel err over {REPS} runs {worst:.2e}  {"ok" if ok else "FAIL"}', flush=True)
     del A, dC, ref
   if verbose: print('RACE SCREEN', 'FAILED' if bad else 'clean', flush=True)
   return bad
