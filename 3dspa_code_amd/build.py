@@ -9,8 +9,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libspa3d_hip.so')
-SOURCES = ['kernels.hip', 'gemm_generic.hip', 'gemm_fast.hip', 'gemm_tnb.hip', 'gemm_rs.hip', 'mlp_fused.hip', 'attention.hip', 'attention_fused.hip', 'qkv_attn.hip', 'ops.hip', 'samplers.hip', 'model.hip']
-F16_SOURCES = ['kernels.hip', 'gemm_generic.hip', 'gemm_fast.hip', 'gemm_tnb.hip', 'gemm_rs.hip', 'mlp_fused.hip', 'attention.hip', 'attention_fused.hip', 'qkv_attn.hip', 'ops.hip', 'model.hip']
+SOURCES = ['kernels.hip', 'gemm_generic.hip', 'gemm_fast.hip', 'gemm_tnb.hip', 'gemm_ntb.hip', 'gemm_rs.hip', 'mlp_fused.hip', 'attention.hip', 'attention_fused.hip', 'qkv_attn.hip', 'ops.hip', 'samplers.hip', 'model.hip']
+F16_SOURCES = ['kernels.hip', 'gemm_generic.hip', 'gemm_fast.hip', 'gemm_tnb.hip', 'gemm_ntb.hip', 'gemm_rs.hip', 'mlp_fused.hip', 'attention.hip', 'attention_fused.hip', 'qkv_attn.hip', 'ops.hip', 'model.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function', '-Wno-inline-asm',
          '-Wno-unused-variable', '-Wno-unused-but-set-variable']
 

@@ -200,6 +200,7 @@ struct spa3d_ctx {
   int nt_stream = 1;      // non-temporal stores for 16-bit outputs >= 512 MB
   int embed_fused = 1;    // input embedding as ONE GEMM over the concatenated K written once, in compact row order (model.hip encode_chunk); gemm_impl 6 = the multi-pass path
   int mlp_fused = 1;      // track-encoder MLP forward as ONE sequence-resident kernel (mlp_fused.hip); gemm_impl 6 = the two tiled GEMMs
+  int nt_big = 1;         // large-register-tile NT kernel (gemm_ntb.hip) for the N = 384 dX GEMMs of the track encoder; 0 off (gemm_impl 6 / 8)
   int rs_gemm = 1;        // K = 384 projections on the row-stationary kernel (gemm_rs.hip); gemm_impl 6 = the tiled kernels; 7 (ops) = required
   int qkv_attn = 0;       // track-encoder QKV projection + attention forward as ONE kernel (qkv_attn.hip): built and measured in round 5, 1.47x SLOWER than the
                           // projection GEMM + attention kernel pair (profiles/r05_qkv_attn_fused.log), so opt-in only: attn_impl 6
@@ -217,13 +218,13 @@ struct spa3d_ctx {
 // K = 384 kernel, no round-5 large-tile dW kernel), 7 (ops only) the row-stationary kernel or an error, 8 the product dispatch without the round-5 large-tile dW kernel, 9 = 3 with every divisible dW on the large-tile kernel
 inline void apply_gemm_impl(spa3d_ctx* c, int v) {
   c->gemm_impl = v == 1 ? 1 : (v >= 2 ? 2 : 0);
-  c->nt_8p = 1; c->nt_8pp = 5; c->tn_8p = 1; c->tn_big = 1; c->nt_occ = 1; c->mlp_fused = 1; c->embed_fused = 1; c->rs_gemm = 1;
+  c->nt_8p = 1; c->nt_8pp = 5; c->tn_8p = 1; c->tn_big = 1; c->nt_big = 1; c->nt_occ = 1; c->mlp_fused = 1; c->embed_fused = 1; c->rs_gemm = 1;
   if (v == 3 || v == 4) { c->nt_8p = 2; c->tn_8p = 2; c->tn_big = 0; }
   if (v == 9) { c->nt_8p = 2; c->tn_8p = 2; c->tn_big = 2; }
   if (v == 4) c->nt_8pp = 1;
   if (v == 5) c->nt_occ = 0;
-  if (v == 6) { c->mlp_fused = 0; c->embed_fused = 0; c->rs_gemm = 0; c->tn_big = 0; }
-  if (v == 8) c->tn_big = 0;
+  if (v == 6) { c->mlp_fused = 0; c->embed_fused = 0; c->rs_gemm = 0; c->tn_big = 0; c->nt_big = 0; }
+  if (v == 8) { c->tn_big = 0; c->nt_big = 0; }
 }
 // attn_impl: 0 product dispatch | 1 generic composition (GEMMs + softmax kernels) | 2 fused kernels (ops: error when unusable) | 3 / 4 fused with the
 // split-pass backward on 4 / 8 waves also where the four-image kernel would run (S <= 160; tests) | 6 fused kernels with the track encoder's QKV projection + attention forward as ONE launch (qkv_attn.hip)
@@ -296,6 +297,12 @@ template <typename T> void gemm_generic(spa3d_ctx* c, const GemmDesc& d);
 // tiled bf16 kernels (gemm_fast.hip).  Return false if the shape/layout is not supported.
 bool gemm_nt_bf16(spa3d_ctx* c, const GemmDesc& d);
 bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d);
+// large-register-tile NT GEMM (gemm_ntb.hip): C[M,N] (16-bit) = A[M,K] . W (+ bias), N a multiple of 384 (tile 256 x 384) or 256 (384 x 256), K % 32 == 0;
+// W pre-packed by gemm_ntb_pack (element (k, n) of W at w[k*sk + n*sn])
+bool gemm_ntb_ok(int K, int N);
+int64_t gemm_ntb_pack_elems(int K, int N);
+template <typename S> void gemm_ntb_pack(spa3d_ctx* c, const S* w, int64_t sk, int64_t sn, int K, int N, bf16_t* wpk);
+bool gemm_ntb(spa3d_ctx* c, const bf16_t* A, int64_t lda, const bf16_t* wpk, const float* bias, bf16_t* C, int64_t ldc, int64_t M, int N, int K);
 // row-stationary K = 384 GEMM (gemm_rs.hip): C[M,N] = A[M,384] . W (+ bias) with W pre-packed into the kernel's fragment stream (element (k, n) of W at w[k*sk + n*sn])
 bool gemm_rs_ok(int K, int N);
 int64_t gemm_rs_pack_elems(int N);

@@ -29,6 +29,13 @@ int op_linear(OpCtx& c, const T* A, const T* B, const float* bias, const T* res,
       gemm_rs_pack<T>(&c, B, N, 1, N, pk);
       return gemm_rs(&c, A, K, pk, bias, C, N, M, N, act == 2 ? res : nullptr, N) ? c.status() : SPA3D_ERR_ARG;
     }
+    if ((impl & 15) == 10) {  // the large-register-tile NT kernel (gemm_ntb.hip) or an error
+      if (act != 0 || res || !gemm_ntb_ok(K, N)) return SPA3D_ERR_ARG;
+      T* pk = c.alloc<T>(gemm_ntb_pack_elems(K, N));
+      if (c.ar.overflow) return SPA3D_ERR_WORKSPACE;
+      gemm_ntb_pack<T>(&c, B, N, 1, K, N, pk);
+      return gemm_ntb(&c, A, K, pk, bias, C, N, M, N, K) ? c.status() : SPA3D_ERR_ARG;
+    }
     if (impl != 1) {
       // impl | 16 (benchmarks): the MLP-in form of the step -- a second output stream (the pre-activation) from the same epilogue
       if (impl & 16) { d.pre_out = c.alloc<T>(M * N); if (c.ar.overflow) return SPA3D_ERR_WORKSPACE; }
@@ -52,7 +59,16 @@ int op_linear_bwd(OpCtx& c, const T* A, const T* B, const T* dC, T* dA, float* d
     d.A = dC; d.B = B; d.C = dA; d.M = M; d.N = K; d.K = N; d.sAm = N; d.sAk = 1; d.sBk = 1; d.sBn = N; d.sCm = K;
     d.Bt = B; d.ldBt = N;
     bool done = false;
-    if constexpr (sizeof(T) == 2) { if (impl != 1) done = gemm_nt_bf16(&c, d); }
+    if constexpr (sizeof(T) == 2) {
+      if (impl == 10) {  // dA on the large-register-tile NT kernel (gemm_ntb.hip) or an error: element (k' = n, n' = k) of B^T is B[k * N + n]
+        if (!gemm_ntb_ok(N, K)) return SPA3D_ERR_ARG;
+        T* pk = c.alloc<T>(gemm_ntb_pack_elems(N, K));
+        if (c.ar.overflow) return SPA3D_ERR_WORKSPACE;
+        gemm_ntb_pack<T>(&c, B, 1, N, N, K, pk);
+        if (!gemm_ntb(&c, dC, N, pk, nullptr, dA, K, M, K, N)) return SPA3D_ERR_ARG;
+        done = true;
+      } else if (impl != 1) done = gemm_nt_bf16(&c, d);
+    }
     if (!done) { if (impl >= 2) return SPA3D_ERR_ARG; gemm_generic<T>(&c, d); }
   }
   if (dB) {  // dB[K,N] = A[M,K]^T . dC[M,N]

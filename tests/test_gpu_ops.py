@@ -326,6 +326,34 @@ def test_linear_bwd_large_register_tile(lib, M, N, K):
   test_linear_bwd_tiled(lib, M, N, K, impl=9)
 
 
+@pytest.mark.parametrize('M,N,K,bias', [(1000, 384, 256, True), (4133, 384, 1536, False), (256, 384, 64, False), (70001, 384, 768, True), (2050, 768, 2304, False),
+                                        (777, 1280, 1536, True), (384, 256, 96, False), (100003, 256, 128, True), (5000, 1536, 1280, False), (255, 1152, 320, True)])
+def test_linear_large_register_tile_nt(lib, M, N, K, bias):
+  """C = A.W (+ bias) on the round-5 large-register-tile NT kernel (csrc/gemm_ntb.hip; impl 10 = that kernel or an error): both workgroup tiles (256 x 384 when
+  384 | N, else 384 x 256), one and several n-tiles, fewer tiles than workgroups and several tiles per workgroup (the phase pipeline runs across tiles), M with a
+  ragged last tile (rows past M are read clamped and their stores dropped by the buffer range check), K from two phases up.  attention.py:106-107,154-183."""
+  test_linear_tiled_nt(lib, M, N, K, 0, False, bias, impl=10)
+
+
+@pytest.mark.parametrize('M,N,K', [(5000, 1536, 384), (3333, 2304, 384), (70001, 768, 384), (1100, 1536, 1280), (257, 64, 768), (30000, 2304, 1280)])
+def test_linear_bwd_dx_large_register_tile(lib, M, N, K):
+  """dA = dC.B^T on the large-register-tile NT kernel (impl 10: B^T packed from the [K][N] weight with swapped strides) -- the dX GEMMs of MLP-in and of
+  q|k|v in the track encoder (output 384 wide, contraction 1536 / 2304) and the 1280-wide ones of the readout stack."""
+  g = torch.Generator().manual_seed(13)
+  B = (torch.randn(K, N, generator=g) / math.sqrt(K)).bfloat16()
+  dC = torch.randn(M, N, generator=g).bfloat16()
+  A = torch.zeros(8, K).bfloat16()   # unused by the dA path
+  dA = torch.full((M, K), float('nan'), device='cuda', dtype=torch.bfloat16)
+  Bd, dCd, Ad = B.cuda(), dC.cuda(), A.cuda()
+  ws = _ws()
+  rc = lib.spa3d_op_linear_bwd(Ad.data_ptr(), Bd.data_ptr(), dCd.data_ptr(), dA.data_ptr(), None, None, M, N, K, BF16, 10, ws.data_ptr(), ws.numel(), _s())
+  assert rc == 0
+  ref = dC.double() @ B.double().T
+  assert not torch.isnan(dA.float()).any()
+  assert rel_err(dA.float(), ref) < 4e-3
+  assert max_abs(dA.float(), ref) < 0.05 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize('bwd_mode', ['1', '2', '3'])
 @pytest.mark.parametrize('nseq,S,H,masked', [(5, 25, 8, True), (3, 129, 8, False), (4, 151, 8, True), (2, 128, 8, False), (3, 40, 2, True),
                                              (17, 151, 8, True), (3, 301, 8, True), (2, 200, 8, False), (2, 320, 4, True), (9, 193, 2, True), (3, 176, 8, True), (2, 160, 4, False)])
