@@ -200,7 +200,7 @@ struct spa3d_ctx {
   int nt_stream = 1;      // non-temporal stores for 16-bit outputs >= 512 MB
   int embed_fused = 1;    // input embedding as ONE GEMM over the concatenated K written once, in compact row order (model.hip encode_chunk); gemm_impl 6 = the multi-pass path
   int mlp_fused = 1;      // track-encoder MLP forward as ONE sequence-resident kernel (mlp_fused.hip); gemm_impl 6 = the two tiled GEMMs
-  int nt_big = 1;         // large-register-tile NT kernel (gemm_ntb.hip) for the N = 384 dX GEMMs of the track encoder; 0 off (gemm_impl 6 / 8)
+  int nt_big = 1;         // large-register-tile NT kernel (gemm_ntb.hip) for the N = 384 dX GEMMs of the track encoder; 2 forced for any M (tests, gemm_impl 9), 0 off (gemm_impl 6 / 8)
   int rs_gemm = 1;        // K = 384 projections on the row-stationary kernel (gemm_rs.hip); gemm_impl 6 = the tiled kernels; 7 (ops) = required
   int qkv_attn = 0;       // track-encoder QKV projection + attention forward as ONE kernel (qkv_attn.hip): built and measured in round 5, 1.47x SLOWER than the
                           // projection GEMM + attention kernel pair (profiles/r05_qkv_attn_fused.log), so opt-in only: attn_impl 6
@@ -219,8 +219,8 @@ struct spa3d_ctx {
 inline void apply_gemm_impl(spa3d_ctx* c, int v) {
   c->gemm_impl = v == 1 ? 1 : (v >= 2 ? 2 : 0);
   c->nt_8p = 1; c->nt_8pp = 5; c->tn_8p = 1; c->tn_big = 1; c->nt_big = 1; c->nt_occ = 1; c->mlp_fused = 1; c->embed_fused = 1; c->rs_gemm = 1;
-  if (v == 3 || v == 4) { c->nt_8p = 2; c->tn_8p = 2; c->tn_big = 0; }
-  if (v == 9) { c->nt_8p = 2; c->tn_8p = 2; c->tn_big = 2; }
+  if (v == 3 || v == 4) { c->nt_8p = 2; c->tn_8p = 2; c->tn_big = 0; c->nt_big = 0; }
+  if (v == 9) { c->nt_8p = 2; c->tn_8p = 2; c->tn_big = 2; c->nt_big = 2; }
   if (v == 4) c->nt_8pp = 1;
   if (v == 5) c->nt_occ = 0;
   if (v == 6) { c->mlp_fused = 0; c->embed_fused = 0; c->rs_gemm = 0; c->tn_big = 0; c->nt_big = 0; }

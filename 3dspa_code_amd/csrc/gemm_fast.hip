@@ -1471,7 +1471,10 @@ bool gemm_tn_bf16(spa3d_ctx* c, const GemmDesc& d) {
   const int64_t tiles = (int64_t)g.tiles_i * g.tiles_n;
   // enough workgroups to fill 256 CUs several times over, but >= 4096 reduction rows per split so the
   // f32 atomic traffic (4 B per output element per split) stays a few % of the tile's MFMA time
-  int64_t splits = std::max<int64_t>(1, std::min<int64_t>((4096 + tiles - 1) / tiles, (M + 4095) / 4096));
+  // (small M -- the latent stacks' dW at M = 1 408: with one split a 144-tile problem is 144 workgroups walking 22 k-steps one memory latency at a time;
+  // there the split goes down to 256 rows as long as the grid stays under ~768 workgroups, whose atomics are a few MB)
+  const int64_t by_rows = std::max<int64_t>((M + 4095) / 4096, std::min<int64_t>(M / 256, (768 + tiles - 1) / tiles));
+  int64_t splits = std::max<int64_t>(1, std::min<int64_t>((4096 + tiles - 1) / tiles, by_rows));
   int64_t rps = ((M + splits - 1) / splits + 63) / 64 * 64;
   splits = (M + rps - 1) / rps;
   g.splits = (int)splits; g.rows_per_split = rps;

@@ -41,6 +41,8 @@ template <typename T> struct Lin {
   T* wt = nullptr;            // [N][K]  (Y = X . W with K contiguous)
   T* wpk = nullptr;           // K = 384: W as the row-stationary kernel's fragment stream (gemm_rs.hip); null = not built
   T* wpk_t = nullptr;         // N = 384 (one segment): W^T as that stream, for dX = dY . W^T
+  T* wnb = nullptr;           // contraction >= 768: W as the large-register-tile NT kernel's fragment stream (gemm_ntb.hip); null = not built
+  T* wnb_t = nullptr;         // W^T as that stream, for dX = dY . W^T (training only)
   const float* bias = nullptr;
   int K = 0, N = 0, nseg = 1, segw = 0;
   int64_t ldn = 0;            // row stride of wn (== N except for column sub-views of a fused matrix)
@@ -116,12 +118,16 @@ template <typename T> struct Net {
         l.wpk_t = alloc<T>(gemm_rs_pack_elems(K));
         gemm_rs_pack<float>(c, l.src[0], 1, l.N, K, l.wpk_t);
       }
+      if (c->nt_big && c->gemm_impl != 1) {  // large-register-tile NT kernel: the shapes it was measured ahead on (profiles/r05_gemm_ntb_*.log) -- contraction >= 768
+        if (K >= 768 && gemm_ntb_ok(K, l.N)) { l.wnb = alloc<T>(gemm_ntb_pack_elems(K, l.N)); gemm_ntb_pack<T>(c, l.wn, l.ldn, 1, K, l.N, l.wnb); }
+        if (G && l.N >= 768 && gemm_ntb_ok(l.N, K)) { l.wnb_t = alloc<T>(gemm_ntb_pack_elems(l.N, K)); gemm_ntb_pack<T>(c, l.wn, 1, l.ldn, l.N, K, l.wnb_t); }
+      }
     }
     return l;
   }
   // columns [seg0*segw, (seg0+nseg)*segw) of a fused matrix as a Lin of its own (no bias)
   static Lin<T> sub_lin(const Lin<T>& l, int seg0, int nseg) {
-    Lin<T> r = l; r.nseg = nseg; r.N = nseg * l.segw; r.bias = nullptr; r.gb = nullptr;
+    Lin<T> r = l; r.nseg = nseg; r.N = nseg * l.segw; r.bias = nullptr; r.gb = nullptr; r.wnb = nullptr; r.wnb_t = nullptr;
     r.wpk = l.wpk && gemm_rs_ok(l.K, r.N) ? l.wpk + gemm_rs_pack_elems(l.segw) * seg0 : nullptr;  // the stream is column-segment-major
     r.wn = l.wn + (int64_t)seg0 * l.segw; r.wt = l.wt + (int64_t)seg0 * l.segw * l.K;
     for (int i = 0; i < 3; ++i) { r.src[i] = i < nseg ? l.src[seg0 + i] : nullptr; r.gw[i] = i < nseg ? l.gw[seg0 + i] : nullptr; }
@@ -209,6 +215,8 @@ template <typename T> struct Net {
     if constexpr (sizeof(T) == 2) {
       if (l.wpk && epi == EPI_NONE && !residual && !out_f32 && !accumulate && !crow_group && !pre_out && M >= 512 &&
           gemm_rs(c, X, ldx ? ldx : l.K, l.wpk, l.bias, (T*)Y, ldy ? ldy : l.N, M, l.N)) return;
+      if (l.wnb && epi == EPI_NONE && !residual && !out_f32 && !accumulate && !crow_group && !pre_out && (M >= 65536 || c->nt_big == 2) &&
+          gemm_ntb(c, X, ldx ? ldx : l.K, l.wnb, l.bias, (T*)Y, ldy ? ldy : l.N, M, l.N, l.K)) return;
     }
     GemmDesc d{};
     d.A = X; d.B = l.wn; d.C = Y; d.M = M; d.N = l.N; d.K = l.K;
@@ -222,6 +230,7 @@ template <typename T> struct Net {
   void lin_bwd_x(const Lin<T>& l, const T* dY, T* dX, int64_t M, const T* gelu_pre = nullptr, int accumulate = 0, int64_t lddx = 0) {
     if constexpr (sizeof(T) == 2) {
       if (l.wpk_t && !accumulate && M >= 512 && gemm_rs(c, dY, l.N, l.wpk_t, nullptr, dX, lddx ? lddx : l.K, M, l.K, gelu_pre, l.K)) return;
+      if (l.wnb_t && !accumulate && !gelu_pre && (M >= 65536 || c->nt_big == 2) && gemm_ntb(c, dY, l.N, l.wnb_t, nullptr, dX, lddx ? lddx : l.K, M, l.K, l.N)) return;
     }
     GemmDesc d{};
     d.A = dY; d.B = l.wn; d.C = dX; d.M = M; d.N = l.K; d.K = l.N;

@@ -160,7 +160,8 @@ int spa3d_adamw_step(float* params, const float* grads, float* m, float* v, int6
  *   "gemm_impl"       0 product dispatch | 1 generic strided MFMA kernel only | 2 tiled kernels | diagnostics that put small problems on the big
  *                     kernels: 3 every eligible GEMM on the 8-phase kernels, 4 the same with the non-persistent 128x384 kernel, 5 without the
  *                     single-buffer short-K kernel, 6 tiled GEMMs without the round-4 / round-5 kernels (MLP forward as two GEMMs, multi-pass input embedding, no row-stationary K = 384 kernel,
- *                     no large-register-tile dW kernel), 8 the product dispatch without the round-5 large-register-tile dW kernel, 9 = 3 with every divisible dW on that kernel.  (The `impl` argument of spa3d_op_linear* takes
+ *                     no large-register-tile kernels), 8 the product dispatch without the round-5 large-register-tile kernels (dW: csrc/gemm_tnb.hip; NT: csrc/gemm_ntb.hip), 9 = 3 with every
+ *                     eligible dW / NT GEMM on those kernels whatever its row count.  (The `impl` argument of spa3d_op_linear* takes
  *                     the same values; spa3d_op_linear: | 16 = also write the pre-activation, the MLP-in form of the step.)
  *   "attn_impl"       0 product dispatch | 1 generic composition | 2 fused kernels | 3, 4 fused with the split-pass backward on 4 / 8 waves (tests) |
  *                     6 fused kernels with the track encoder's QKV projection + attention forward as one launch (built in round 5, slower than the pair: opt-in)
@@ -227,7 +228,8 @@ int spa3d_op_sin_embed(const float* x, int64_t rows, int32_t C, int32_t nf, void
 /* C[M,N] = act(A[M,K] @ B[K,N] + bias) (+ residual); A,B,C,residual dense row-major `dtype`;
  * act: 0 none, 1 tanh-gelu, 2 = no activation and `residual` is not added but holds a pre-activation: C = (A @ B + bias) o gelu'(residual), the MLP backward's
  * dh = (dy . W_out^T) o gelu'(hpre).  impl: 0 auto, 1 generic kernel, 2 tiled bf16 kernel (error if unusable), ... as "gemm_impl" above; 7 = the row-stationary
- * K = 384 kernel (csrc/gemm_rs.hip: 16-bit, 128 | N <= 2304, act 0 or 2) or an error. */
+ * K = 384 kernel (csrc/gemm_rs.hip: 16-bit, 128 | N <= 2304, act 0 or 2) or an error; 10 = the large-register-tile NT kernel (csrc/gemm_ntb.hip: 16-bit,
+ * 384 | N or 256 | N, 32 | K >= 64, act 0, no residual) or an error -- spa3d_op_linear_bwd: its dA on that kernel. */
 int spa3d_op_linear(const void* A, const void* B, const float* bias, const void* residual, void* C,
                     int64_t M, int32_t N, int32_t K, int32_t act, int32_t dtype, int32_t impl,
                     void* ws, int64_t ws_bytes, void* stream);
