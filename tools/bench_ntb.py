@@ -28,10 +28,11 @@ for (M, N, K, bias, what) in shapes:
       e0.record(); f(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     ts.sort(); res[impl] = (ts[3], Cd)
   if only < 0:
+    same = bool(torch.equal(res[0][1], res[10][1]))   # the WHOLE output, bit for bit (no atomics in either kernel: any difference is a race or an addressing bug)
     d = (res[0][1][:65536].float() - res[10][1][:65536].float()); err = float(d.norm() / res[0][1][:65536].float().norm())
     ref = (A[:4096].float() @ W.float()) + (b if bias else 0); e10 = float((res[10][1][:4096].float() - ref).norm() / ref.norm())
     print(f'NT M={M} N={N} K={K} bias={bias} [{what}]: product {res[0][0]:7.3f} ms ({2.0 * M * N * K / res[0][0] / 1e9:7.1f} TF/s)   large tile {res[10][0]:7.3f} ms '
-          f'({2.0 * M * N * K / res[10][0] / 1e9:7.1f} TF/s)   x{res[0][0] / res[10][0]:.3f}   rel diff {err:.2e}  vs fp32 ref {e10:.2e}', flush=True)
+          f'({2.0 * M * N * K / res[10][0] / 1e9:7.1f} TF/s)   x{res[0][0] / res[10][0]:.3f}   rel diff {err:.2e}  whole output identical: {same}  vs fp32 ref {e10:.2e}', flush=True)
   else:
     t = res[only][0]; print(f'NT M={M} N={N} K={K} impl {only}: {t:7.3f} ms ({2.0 * M * N * K / t / 1e9:7.1f} TF/s)', flush=True)
   del A, W
