@@ -341,6 +341,7 @@ static void launch_ntb(spa3d_ctx* c, NtbArgs g) {
 bool gemm_ntb(spa3d_ctx* c, const bf16_t* A, int64_t lda, const bf16_t* wpk, const float* bias, bf16_t* C, int64_t ldc, int64_t M, int N, int K) {
   if (!wpk || !gemm_ntb_ok(K, N) || M < 1) return false;
   if (lda % 8 || ldc % 8 || lda > (1 << 20) || ldc > (1 << 20) || (((uintptr_t)A | (uintptr_t)C | (uintptr_t)wpk) & 15) || (bias && ((uintptr_t)bias & 15))) return false;
+  if (((M + 255) / 256) * (int64_t)(N / 256 + 1) > (int64_t(1) << 30)) return false;   // the kernel's tile ids are 32-bit
   if (c->dry) return true;
   NtbArgs g{};
   g.A = A; g.lda = lda; g.wpk = (const char*)wpk; g.C = C; g.ldc = ldc; g.bias = bias; g.M = M; g.N = N; g.K = K;
