@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ntb_kernel(NtbArgs g) {
           }
           uint2 pk;
           pk.x = ntb_pack2(v0, v1); pk.y = ntb_pack2(v2, v3);
-          *(uint2*)(buf + er * 144 + (32 * q + 8 * gq + 4 * ehh) * 2) = pk;
+          *(uint2*)(buf + er * 144 + (32 * q + 8 * gq + 4 * (ehh ^ ((er >> 3) & 1))) * 2) = pk;   // rows r and r + 8 share banks at this stride: their 8-B halves of a 16-B chunk are swapped
         });
       });
     };
@@ -290,7 +290,11 @@ __global__ __launch_bounds__(256, 1) void gemm_ntb_kernel(NtbArgs g) {
       const char* buf = stg + (r & 1) * 4608;
       ntb_u32x4 rv[4];
       __builtin_amdgcn_sched_barrier(0);
-      nt_for<0, 4>([&](auto it_) { constexpr int it = decltype(it_)::v; rv[it] = *(const ntb_u32x4*)(buf + (8 * it + (lane >> 3)) * 144 + (lane & 7) * 16); });
+      nt_for<0, 4>([&](auto it_) {
+        constexpr int it = decltype(it_)::v;
+        const ntb_u32x4 t4 = *(const ntb_u32x4*)(buf + (8 * it + (lane >> 3)) * 144 + (lane & 7) * 16);
+        rv[it] = (it & 1) ? ntb_u32x4{t4[2], t4[3], t4[0], t4[1]} : t4;   // rows 8 .. 15 and 24 .. 31 of the round were written with the halves swapped
+      });
       __builtin_amdgcn_sched_barrier(0);   // (the fences keep one round's accumulator copies live at a time: left free, hipcc hoists all 256 AGPR reads and spills)
       if constexpr (r + 1 < NR) conv_write(NtIC<(r + 1 < NR ? r + 1 : 0)>{});
       __builtin_amdgcn_sched_barrier(0);
