@@ -389,6 +389,9 @@ void k_layernorm_bwd(spa3d_ctx* c, const T* x, const float* scale, const float* 
   ps.tag(rows, d, add ? 1 : 0, 0);
   constexpr int gcapb = 1024;
   unsigned g = (unsigned)std::min<int64_t>(cdiv(rows, 4), d <= 512 ? gcapb : 2 * gcapb);  // measured: 1024 blocks at d = 384, 2048 at d = 1280
+  // few rows (the latent stacks: 1 408): one block per 4 rows means 352 blocks each adding its d partial sums into the SAME d addresses -- 103 us for 3 MB;
+  // 32 rows per block there
+  if (rows <= 16384) g = (unsigned)std::min<int64_t>(g, std::max<int64_t>(64, cdiv(rows, 32)));
   constexpr int NV = VecOf<T>::N;
   const bool al = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)add)) & 15) == 0;
   if (d % NV == 0 && al && d <= 64 * NV * 4) {
@@ -720,7 +723,7 @@ void k_colsum(spa3d_ctx* c, const T* x, int64_t rows, int n, int64_t ld_, float*
   constexpr int NV = VecOf<T>::N;
   if (n % NV == 0 && ld_ % NV == 0 && (((uintptr_t)x) & 15) == 0) {
     const int64_t gx = cdiv(n / NV, 32);
-    int64_t sp = std::max<int64_t>(1, std::min<int64_t>(cdiv(rows, 512), 2048 / gx + 1));
+    int64_t sp = std::max<int64_t>(1, std::min<int64_t>(cdiv(rows, 64), 2048 / gx + 1));   // (was rows / 512: at 1 408 rows three row splits, 59 dependent loads per thread)
     int64_t rpb_ = cdiv(rows, sp);
     colsum_vec_kernel<T><<<dim3((unsigned)gx, (unsigned)cdiv(rows, rpb_)), 256, 0, c->stream>>>(x, rows, n, ld_, out, rpb_, rgroup, rskip);
     SPA_LAUNCH_CHECK(c);
