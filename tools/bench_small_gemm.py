@@ -7,6 +7,7 @@ if os.environ.get('SPA3D_TOOL_LIB'): spa3d._lib.LIB_PATH = os.environ['SPA3D_TOO
 lib = spa3d._lib.load()
 s = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 ws = torch.empty(1 << 26, dtype=torch.uint8, device='cuda')
+IMPL = int(os.environ.get('IMPL', 0))   # gemm_impl of the forward / dX calls (3 = every eligible NT GEMM on the 8-phase kernels whatever M)
 def timeit(f, n=50):
   assert f() == 0; torch.cuda.synchronize()
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -18,8 +19,8 @@ for (M, N, K) in ((1408, 768, 512), (1408, 768, 1152), (1408, 2048, 1152), (1408
   A = torch.randn(M, K, device='cuda').bfloat16(); W = (torch.randn(K, N, device='cuda') / K ** 0.5).bfloat16(); dC = torch.randn(M, N, device='cuda').bfloat16()
   dB = torch.zeros(K, N, device='cuda'); Cd = torch.empty(M, N, device='cuda', dtype=torch.bfloat16); dA = torch.empty(M, K, device='cuda', dtype=torch.bfloat16)
   t_tn = timeit(lambda: lib.spa3d_op_linear_bwd(A.data_ptr(), W.data_ptr(), dC.data_ptr(), None, dB.data_ptr(), None, M, N, K, 1, 0, ws.data_ptr(), ws.numel(), s()))
-  t_nt = timeit(lambda: lib.spa3d_op_linear(A.data_ptr(), W.data_ptr(), None, None, Cd.data_ptr(), M, N, K, 0, 1, 0, ws.data_ptr(), ws.numel(), s()))
-  t_dx = timeit(lambda: lib.spa3d_op_linear_bwd(A.data_ptr(), W.data_ptr(), dC.data_ptr(), dA.data_ptr(), None, None, M, N, K, 1, 0, ws.data_ptr(), ws.numel(), s()))
+  t_nt = timeit(lambda: lib.spa3d_op_linear(A.data_ptr(), W.data_ptr(), None, None, Cd.data_ptr(), M, N, K, 0, 1, IMPL, ws.data_ptr(), ws.numel(), s()))
+  t_dx = timeit(lambda: lib.spa3d_op_linear_bwd(A.data_ptr(), W.data_ptr(), dC.data_ptr(), dA.data_ptr(), None, None, M, N, K, 1, IMPL, ws.data_ptr(), ws.numel(), s()))
   ref = A.float().T @ dC.float()
   lib.spa3d_op_linear_bwd(A.data_ptr(), W.data_ptr(), dC.data_ptr(), None, dB.data_ptr(), None, M, N, K, 1, 0, ws.data_ptr(), ws.numel(), s())
   err = float((dB - ref).norm() / ref.norm())
