@@ -46,6 +46,15 @@ typedef __attribute__((ext_vector_type(8))) __bf16 mfma16x8;
 #define DOT2C_F32_16 "v_dot2c_f32_bf16"
 #define ONES2_16 0x3F803F80u  // (1.0, 1.0)
 #endif
+// two f32 -> one dword of two 16-bit values (low half = a): ONE v_cvt_pk_bf16_f32 (fp16 build: two converts + a pack).  The element-wise form
+// (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16) compiles to a convert per element plus a shift / mask / or: three VALU operations per pair in every GEMM epilogue.
+#if SPA_F16
+typedef __attribute__((ext_vector_type(2))) _Float16 spa_h16x2;
+#else
+typedef __attribute__((ext_vector_type(2))) __bf16 spa_h16x2;
+#endif
+typedef __attribute__((ext_vector_type(2))) float spa_f32x2;
+__device__ __forceinline__ unsigned f2bf_pack2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(spa_f32x2{a, b}, spa_h16x2)); }
 // the two 16-bit halves of a packed dword as f32
 __device__ __forceinline__ float unpack_lo(unsigned u) { return bf2f((bf16_t)(u & 0xffffu)); }
 __device__ __forceinline__ float unpack_hi(unsigned u) { return bf2f((bf16_t)(u >> 16)); }

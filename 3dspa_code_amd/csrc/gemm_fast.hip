@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
     if (g.pre_out) {
       uint4 p4; unsigned* pp = (unsigned*)&p4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pp[r] = (unsigned)f2bf(v[2 * r]) | ((unsigned)f2bf(v[2 * r + 1]) << 16);
+      for (int r = 0; r < 4; ++r) pp[r] = f2bf_pack2(v[2 * r], v[2 * r + 1]);
       *(uint4*)(g.pre_out + ci) = p4;
     }
     if (g.epi == EPI_GELU) {
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
         for (int r = 0; r < 4; ++r) { v[2 * r] += unpack_lo(op[r]); v[2 * r + 1] += unpack_hi(op[r]); } }
       uint4 o4; unsigned* op = (unsigned*)&o4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) op[r] = (unsigned)f2bf(v[2 * r]) | ((unsigned)f2bf(v[2 * r + 1]) << 16);
+      for (int r = 0; r < 4; ++r) op[r] = f2bf_pack2(v[2 * r], v[2 * r + 1]);
       *cp = o4;
     }
   }
@@ -329,7 +329,7 @@ __device__ __forceinline__ void nt_store8(const NtArgs& g, int64_t gm, int gn, f
   if (g.pre_out) {
     uint4 p4; unsigned* pp = (unsigned*)&p4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pp[r] = (unsigned)f2bf(v[2 * r]) | ((unsigned)f2bf(v[2 * r + 1]) << 16);
+    for (int r = 0; r < 4; ++r) pp[r] = f2bf_pack2(v[2 * r], v[2 * r + 1]);
     *(uint4*)(g.pre_out + ci) = p4;
   }
   if (g.epi == EPI_GELU) {
@@ -357,7 +357,7 @@ __device__ __forceinline__ void nt_store8(const NtArgs& g, int64_t gm, int gn, f
       for (int r = 0; r < 4; ++r) { v[2 * r] += unpack_lo(op[r]); v[2 * r + 1] += unpack_hi(op[r]); } }
     uint4 o4; unsigned* op = (unsigned*)&o4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) op[r] = (unsigned)f2bf(v[2 * r]) | ((unsigned)f2bf(v[2 * r + 1]) << 16);
+    for (int r = 0; r < 4; ++r) op[r] = f2bf_pack2(v[2 * r], v[2 * r + 1]);
     if (g.nt_store) { typedef __attribute__((ext_vector_type(4))) unsigned u32x4; __builtin_nontemporal_store(u32x4{o4.x, o4.y, o4.z, o4.w}, (u32x4*)cp); }
     else *cp = o4;
   }
@@ -381,7 +381,7 @@ __device__ __forceinline__ uint4 nt_compute8_aux(const NtArgs& g, float (&v)[8],
   }
   uint4 o4; unsigned* op = (unsigned*)&o4;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) op[r] = (unsigned)f2bf(v[2 * r]) | ((unsigned)f2bf(v[2 * r + 1]) << 16);
+  for (int r = 0; r < 4; ++r) op[r] = f2bf_pack2(v[2 * r], v[2 * r + 1]);
   return o4;
 }
 
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(512, (WMT * WNT <= 8 ? 4 : 2)) void gemm_nt8p_kerne
           for (int r = 0; r < 4; ++r) {
             const float y0 = (g.alpha * v[2 * r] + bv[CONSTC ? 0 : it][2 * r]) + xr * wv[CONSTC ? 0 : it][2 * r];
             const float y1 = (g.alpha * v[2 * r + 1] + bv[CONSTC ? 0 : it][2 * r + 1]) + xr * wv[CONSTC ? 0 : it][2 * r + 1];
-            op[r] = (unsigned)f2bf(y0) | ((unsigned)f2bf(y1) << 16);
+            op[r] = f2bf_pack2(y0, y1);
           }
           *(uint4*)((bf16_t*)g.C + (int64_t)crow_i[half][it] * g.ldc + gn) = o4;
         }

@@ -35,14 +35,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float ntb_f32x4;
 typedef mfma16x8 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned ntb_u32x4;
-typedef __attribute__((ext_vector_type(2))) float ntb_f32x2;
-#if SPA_F16
-typedef __attribute__((ext_vector_type(2))) _Float16 ntb_h16x2;
-#else
-typedef __attribute__((ext_vector_type(2))) __bf16 ntb_h16x2;
-#endif
-// two f32 -> one packed pair (v_cvt_pk_bf16_f32; element-wise f2bf + shifts costs three VALU operations per pair)
-__device__ __forceinline__ unsigned ntb_pack2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(ntb_f32x2{a, b}, ntb_h16x2)); }
 
 #define NTB_PH 40960
 #define NTB_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -279,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ntb_kernel(NtbArgs g) {
             v0 += b4[0]; v1 += b4[1]; v2 += b4[2]; v3 += b4[3];
           }
           uint2 pk;
-          pk.x = ntb_pack2(v0, v1); pk.y = ntb_pack2(v2, v3);
+          pk.x = f2bf_pack2(v0, v1); pk.y = f2bf_pack2(v2, v3);
           *(uint2*)(buf + er * 144 + (32 * q + 8 * gq + 4 * (ehh ^ ((er >> 3) & 1))) * 2) = pk;   // rows r and r + 8 share banks at this stride: their 8-B halves of a 16-B chunk are swapped
         });
       });

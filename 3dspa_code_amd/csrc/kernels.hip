@@ -110,7 +110,7 @@ __device__ __forceinline__ void store_vec(T* p, const float (&f)[NV]) {
   if constexpr (sizeof(T) == 4) { *(float4*)p = make_float4(f[0], f[1], f[2], f[3]); }
   else { unsigned u[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) u[i] = (unsigned)f2bf(f[2 * i]) | ((unsigned)f2bf(f[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) u[i] = f2bf_pack2(f[2 * i], f[2 * i + 1]);
     *(uint4*)p = make_uint4(u[0], u[1], u[2], u[3]); }
 }
 // the 16 bytes of load_vec kept packed (half the registers of the unpacked floats while several rows are in flight)

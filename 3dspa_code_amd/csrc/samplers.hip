@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void sample_dino_kernel(const float* __restric
         const float v0 = blend(a.x, b.x, cc.x, d.x, c.wx, c.wy), v1 = blend(a.y, b.y, cc.y, d.y, c.wx, c.wy);
         const float v2 = blend(a.z, b.z, cc.z, d.z, c.wx, c.wy), v3 = blend(a.w, b.w, cc.w, d.w, c.wx, c.wy);
         if constexpr (sizeof(TOUT) == 4) *(float4*)(o + ch) = make_float4(v0, v1, v2, v3);
-        else { uint2 u; u.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16); u.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16); *(uint2*)(o + ch) = u; }
+        else { uint2 u; u.x = f2bf_pack2(v0, v1); u.y = f2bf_pack2(v2, v3); *(uint2*)(o + ch) = u; }
       }
     } else {
       for (int ch = lane; ch < D; ch += 64) st(o + ch, blend(r00[ch], r01[ch], r10[ch], r11[ch], c.wx, c.wy));
