@@ -113,8 +113,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs g) {
   char* Ks = smem; char* Vs = smem + img_bytes(S_pad); float* kbias = (float*)(smem + 2 * img_bytes(S_pad));
   constexpr bool WIDE = fwd_wide(KT, NW);  // output rows through a wave tile (not where it would cost the second workgroup per CU)
   char* wt = (char*)(kbias + S_pad) + (threadIdx.x >> 6) * WTILE;
-  const int64_t prob = map_prob(blockIdx.x, g.nprob / g.H, g.H);
-  const int64_t seq = prob / g.H; const int h = (int)(prob - seq * g.H);
+  unsigned seq_u, h_u; map_prob32(blockIdx.x, (unsigned)g.nprob / (unsigned)g.H, (unsigned)g.H, seq_u, h_u);
+  const int64_t seq = seq_u; const int h = (int)h_u;
   const int64_t row0 = g.seq_off ? (int64_t)g.seq_off[seq] : seq * g.S;       // first row of the sequence
   const int S = g.seq_off ? g.seq_off[seq + 1] - (int)row0 : g.S, E = g.H * DH;  // its length (wave-uniform)
   const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
@@ -260,8 +260,9 @@ __global__ __launch_bounds__(256, 2) void xattn_fwd_kernel(XAttnArgs g) {
   constexpr int KT = XCHUNK / 16, NW = 4, S_pad = XCHUNK, RPP = NW * 16, NP = S_pad / RPP, NT = KT / NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem; char* Vs = smem + img_bytes(S_pad); float* kbias = (float*)(smem + 2 * img_bytes(S_pad));
-  const int64_t pi = blockIdx.x, prob = pi / g.nsplit; const int sp = (int)(pi - prob * g.nsplit);
-  const int64_t seq = prob / g.H; const int h = (int)(prob - seq * g.H);
+  const unsigned pi_u = blockIdx.x, prob_u = pi_u / (unsigned)g.nsplit, seq_u = prob_u / (unsigned)g.H;   // 32-bit: nprob * nsplit < 2^31 (xattn_fwd)
+  const int64_t pi = pi_u, prob = prob_u; const int sp = (int)(pi_u - prob_u * (unsigned)g.nsplit);
+  const int64_t seq = seq_u; const int h = (int)(prob_u - seq_u * (unsigned)g.H);
   const int64_t qrow0 = seq * g.Sq, krow0 = seq * g.Sk + (int64_t)sp * S_pad;
   const int Sq = g.Sq, kn = min(S_pad, g.Sk - sp * S_pad), QT = (Sq + 15) / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fq = lane >> 4;
@@ -826,12 +827,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd8_kernel(AttnBwdArgs g) {
 
   for (int t = tid; t < 2 * DH; t += 512) sscale[t] = t < DH ? g.sq[t] : g.sk[t - DH];
   __syncthreads();
-  const int64_t nseq = g.nprob / g.H;
+  const int64_t nseq = (unsigned)g.nprob / (unsigned)g.H;
   const int64_t nwork = X ? g.nprob * g.nsplit : g.nprob;
   for (int64_t pi = blockIdx.x; pi < nwork; pi += gridDim.x) {
-    const int64_t prob = X ? pi / g.nsplit : map_prob(pi, nseq, g.H);
-    const int sp = X ? (int)(pi - prob * g.nsplit) : 0;
-    const int64_t seq = prob / g.H; const int h = (int)(prob - seq * g.H);
+    // (32-bit index arithmetic, one or two divisions: the launchers refuse nprob * nsplit >= 2^31)
+    unsigned seq_u, h_u, prob_u; int sp = 0;
+    if constexpr (X) { prob_u = (unsigned)pi / (unsigned)g.nsplit; sp = (int)((unsigned)pi - prob_u * (unsigned)g.nsplit); seq_u = prob_u / (unsigned)g.H; h_u = prob_u - seq_u * (unsigned)g.H; }
+    else { map_prob32((unsigned)pi, (unsigned)nseq, (unsigned)g.H, seq_u, h_u); prob_u = seq_u * (unsigned)g.H + h_u; }
+    const int64_t prob = prob_u, seq = seq_u; const int h = (int)h_u;
     const int64_t row0 = X ? seq * g.S : g.seq_off ? (int64_t)g.seq_off[seq] : seq * g.S;   // first query-side row
     const int S = (!X && g.seq_off) ? g.seq_off[seq + 1] - (int)row0 : g.S;               // query-side rows
     const int64_t krow0 = X ? seq * g.Sk + (int64_t)sp * S_pad : row0;                   // first key-side row
@@ -949,8 +952,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_split_kernel(AttnBwdArgs 
   __syncthreads();
   const int64_t nseq = g.nprob / g.H;
   for (int64_t pi = blockIdx.x; pi < g.nprob; pi += gridDim.x) {
-    const int64_t prob = map_prob(pi, nseq, g.H);
-    const int64_t seq = prob / g.H; const int h = (int)(prob - seq * g.H);
+    unsigned seq_u, h_u; map_prob32((unsigned)pi, (unsigned)nseq, (unsigned)g.H, seq_u, h_u);
+    const int64_t seq = seq_u; const int h = (int)h_u;
     const int64_t row0 = g.seq_off ? (int64_t)g.seq_off[seq] : seq * g.S;
     const int S = g.seq_off ? g.seq_off[seq + 1] - (int)row0 : g.S;
     const int QT = (S + 15) / 16;
@@ -1139,6 +1142,7 @@ bool attn_fused_bwd_bf16(spa3d_ctx* c, const bf16_t* q, const bf16_t* k, const b
   if (ldq % 8 || ldk % 8 || ldv % 8 || !al16(q) || !al16(k) || !al16(v) || !al16(o) || !al16(d_o) || !al16(dq) || !al16(dk) || !al16(dv) ||
       !al16(sq) || !al16(sk))
     return false;
+  if (nseq * H > 0x7fffffffLL) return false;   // the kernels index problems in 32 bits
   if (c->dry) return true;
   AttnBwdArgs a; a.q = q; a.k = k; a.v = v; a.o = o; a.d_o = d_o; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.sq = sq; a.sk = sk; a.km = km;
   a.lse = lse; a.S = Sk; a.H = H; a.nprob = nseq * H; a.dq = dq; a.dk = dk; a.dv = dv; a.dsq = dsq; a.dsk = dsk; a.seq_off = seq_off;

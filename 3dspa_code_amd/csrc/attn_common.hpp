@@ -58,6 +58,15 @@ __device__ __forceinline__ int64_t map_prob(int64_t b, int64_t nseq, int H) {
   const int64_t x = b & 7, i = b >> 3;
   return ((i / H) * 8 + x) * H + (i % H);
 }
+// The same map in 32 bits with ONE division, returning (sequence, head) directly (every launcher refuses nseq * H * nsplit >= 2^31).  The 64-bit form above costs
+// ~400 scalar instructions per problem (four 64-bit divisions: the map's / and %, then prob / H and its remainder), all of them in front of the problem's
+// first global load in a persistent kernel.
+__device__ __forceinline__ void map_prob32(unsigned b, unsigned nseq, unsigned H, unsigned& seq, unsigned& h) {
+  const unsigned nfull = nseq & ~7u;
+  if (b >= nfull * H) { seq = b / H; h = b - seq * H; return; }
+  const unsigned i = b >> 3, q = i / H;
+  seq = q * 8 + (b & 7); h = i - q * H;
+}
 
 // Wave-private LDS tile (16 rows): results held as (row fr, d = 16dt + 4fq + r) -- 8 bytes per lane and dt, i.e. 32-byte pieces of 16
 // rows per store instruction -- are turned into 64 contiguous bytes per row and instruction (the staging loads' shape) on the way out.
