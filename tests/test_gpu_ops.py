@@ -327,7 +327,8 @@ def test_linear_bwd_large_register_tile(lib, M, N, K):
 
 
 @pytest.mark.parametrize('M,N,K,bias', [(1000, 384, 256, True), (4133, 384, 1536, False), (256, 384, 64, False), (70001, 384, 768, True), (2050, 768, 2304, False),
-                                        (777, 1280, 1536, True), (384, 256, 96, False), (100003, 256, 128, True), (5000, 1536, 1280, False), (255, 1152, 320, True)])
+                                        (777, 1280, 1536, True), (384, 256, 96, False), (100003, 256, 128, True), (5000, 1536, 1280, False), (255, 1152, 320, True),
+                                        (1, 384, 64, True), (33, 256, 2304, False), (65537, 384, 1536, False)])
 def test_linear_large_register_tile_nt(lib, M, N, K, bias):
   """C = A.W (+ bias) on the round-5 large-register-tile NT kernel (csrc/gemm_ntb.hip; impl 10 = that kernel or an error): both workgroup tiles (256 x 384 when
   384 | N, else 384 x 256), one and several n-tiles, fewer tiles than workgroups and several tiles per workgroup (the phase pipeline runs across tiles), M with a
